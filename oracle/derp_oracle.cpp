@@ -1,0 +1,1437 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY. Not part of the product path.
+//
+// CPU restatement of facebook360_dep's depth_estimation hot path,
+// plain C++17, no third-party dependencies. Only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg may load this library.
+//
+// Each function cites the reference file:line it follows (paths relative to
+// /root/reference/). Pinning status:
+//   * Camera maths          — pinned by the reference's own known-answer tests
+//                             (source/test/util/{FTheta,Rectilinear,Orthographic}Test.cpp)
+//                             and by vectors generated from scripts/util/camera.py.
+//   * cost / propagation / filters / upsample — PARITY UNPINNED by the reference
+//     (its only checks need S3 datasets); OpenCV-defined arithmetic restated in
+//     oracle_cv.h is likewise unpinned. The restatement + committed goldens are the pin.
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <random>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "oracle_camera.h"
+#include "oracle_cv.h"
+
+namespace oracle {
+
+// ---- constants: Derp.h:26-48, DerpUtil.h:22-43 ----
+static const int kSearchWindowRadius = 1;
+static const int kMinOverlappingCams = 2;
+static const int kNumDepths = 150;
+static const float kRandomPropMaxCost = 5.0;
+static const float kRandomPropHighVarDeviation = 0.1;
+static const int kMedianFilterRadius = 1;
+static const int kBilateralSpaceRadiusMin = 1;
+static const int kBilateralSpaceRadiusMax = 5;
+static const float kBilateralSigma = 0.005;
+static const float kBilateralWeightR = 1.0;
+static const float kBilateralWeightG = 1.0;
+static const float kBilateralWeightB = 0.5;
+static const float kLevelScale = 0.9f;
+static const float kRgbWeights[3] = {0.3333f, 0.3334f, 0.3333f};
+static const float kMinVar = 1.0f / 12.0f / 65025.0f;
+static const int kCandidateTemplate[9][2] =
+    {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-2, -2}, {2, -2}, {-2, 2}, {2, 2}};
+
+template <typename T>
+static inline T clampT(const T& x, const T& a, const T& b) { // MathUtil.h:37-39
+  return x < a ? a : x > b ? b : x;
+}
+
+// ThreadPool.h:23-57 runs one task per row in batches; results do not depend on
+// the batching, so a plain strided parallel-for is equivalent.
+static void parallelFor(int begin, int end, int threads, const std::function<void(int)>& fn) {
+  int n = threads < 0 ? std::max(1u, std::thread::hardware_concurrency()) : threads;
+  if (n <= 1 || end - begin <= 1) {
+    for (int i = begin; i < end; ++i) {
+      fn(i);
+    }
+    return;
+  }
+  std::atomic<int> next(begin);
+  std::vector<std::thread> pool;
+  for (int t = 0; t < n; ++t) {
+    pool.emplace_back([&] {
+      for (;;) {
+        const int i = next.fetch_add(1);
+        if (i >= end) {
+          return;
+        }
+        fn(i);
+      }
+    });
+  }
+  for (auto& th : pool) {
+    th.join();
+  }
+}
+
+// ---- CvUtil.h:78-120: clampToEdge / bilerp / getPixelBilinear ----
+// NOTE (SURVEY §7 "Truncating bilinear"): for Vec<ushort,3> the per-channel call
+// resolves to the scalar template with T=ushort, whose return type truncates the
+// float expression to an integer. Vec2f / float stay float.
+template <typename T>
+static inline const T& clampToEdge(const Img<T>& src, int x, int y) {
+  return src.at(clampT(y, 0, src.h - 1), clampT(x, 0, src.w - 1));
+}
+static inline uint16_t
+bilerpU16(uint16_t p00, uint16_t p01, uint16_t p10, uint16_t p11, float xw, float yw) {
+  return (uint16_t)(
+      (1 - xw) * (1 - yw) * p00 + xw * (1 - yw) * p01 + (1 - xw) * yw * p10 + xw * yw * p11);
+}
+static inline float bilerpF(float p00, float p01, float p10, float p11, float xw, float yw) {
+  return (1 - xw) * (1 - yw) * p00 + xw * (1 - yw) * p01 + (1 - xw) * yw * p10 + xw * yw * p11;
+}
+static inline Px3w getPixelBilinear(const Img<Px3w>& src, const float x, const float y) {
+  const float xf = std::round(x);
+  const float yf = std::round(y);
+  const int xi = xf;
+  const int yi = yf;
+  const Px3w& p00 = clampToEdge(src, xi - 1, yi - 1);
+  const Px3w& p01 = clampToEdge(src, xi, yi - 1);
+  const Px3w& p10 = clampToEdge(src, xi - 1, yi);
+  const Px3w& p11 = clampToEdge(src, xi, yi);
+  const float xw = x - xf + 0.5f, yw = y - yf + 0.5f;
+  Px3w r;
+  for (int i = 0; i < 3; ++i) {
+    r.c[i] = bilerpU16(p00.c[i], p01.c[i], p10.c[i], p11.c[i], xw, yw);
+  }
+  return r;
+}
+static inline Px2f getPixelBilinear(const Img<Px2f>& src, const float x, const float y) {
+  const float xf = std::round(x);
+  const float yf = std::round(y);
+  const int xi = xf;
+  const int yi = yf;
+  const Px2f& p00 = clampToEdge(src, xi - 1, yi - 1);
+  const Px2f& p01 = clampToEdge(src, xi, yi - 1);
+  const Px2f& p10 = clampToEdge(src, xi - 1, yi);
+  const Px2f& p11 = clampToEdge(src, xi, yi);
+  const float xw = x - xf + 0.5f, yw = y - yf + 0.5f;
+  Px2f r;
+  for (int i = 0; i < 2; ++i) {
+    r.c[i] = bilerpF(p00.c[i], p01.c[i], p10.c[i], p11.c[i], xw, yw);
+  }
+  return r;
+}
+static inline float getPixelBilinear(const Img<float>& src, const float x, const float y) {
+  const float xf = std::round(x);
+  const float yf = std::round(y);
+  const int xi = xf;
+  const int yi = yf;
+  return bilerpF(
+      clampToEdge(src, xi - 1, yi - 1),
+      clampToEdge(src, xi, yi - 1),
+      clampToEdge(src, xi - 1, yi),
+      clampToEdge(src, xi, yi),
+      x - xf + 0.5f,
+      y - yf + 0.5f);
+}
+
+// ---- DerpUtil.cpp:38-73 ----
+static inline V3 dstToWorldPoint(
+    const Camera& camDst, const int x, const int y, const float disparity, const int dstW, const int dstH) {
+  V2 p = {(x + 0.5) / dstW, (y + 0.5) / dstH};
+  if (!camDst.isNormalized()) {
+    p = {p.x * camDst.resolution.x, p.y * camDst.resolution.y};
+  }
+  return camDst.rig(p, 1.0f / disparity);
+}
+static inline bool
+worldToSrcPoint(V2& pSrc, const V3& pWorld, const Camera& camSrc, const int srcW, const int srcH) {
+  if (!camSrc.sees(pWorld, pSrc)) {
+    return false;
+  }
+  if (camSrc.isNormalized()) {
+    pSrc.x *= srcW;
+    pSrc.y *= srcH;
+  }
+  return true;
+}
+
+// ---- DerpUtil.cpp:126-162 ----
+static inline std::pair<float, float> computeSSD(
+    const Img<Px3w>& dstColor,
+    const int x,
+    const int y,
+    const Px3w& dstBias,
+    const Img<Px3w>& dstSrcColor,
+    const float xDstSrc,
+    const float yDstSrc,
+    const Px3w& dstSrcBias,
+    const int radius) {
+  float bias[3];
+  for (int c = 0; c < 3; ++c) {
+    bias[c] = float(dstBias.c[c]) - float(dstSrcBias.c[c]);
+  }
+  std::pair<float, float> ssd = {0.0f, 0.0f};
+  for (int dx = -radius; dx <= radius; ++dx) {
+    for (int dy = -radius; dy <= radius; ++dy) {
+      const Px3w& cDstW = dstColor.at(y + dy, x + dx);
+      const Px3w cSrcW = getPixelBilinear(dstSrcColor, xDstSrc + dx, yDstSrc + dy);
+      float diffBias[3], diffNoBias[3];
+      for (int c = 0; c < 3; ++c) {
+        diffBias[c] = float(cDstW.c[c]) - float(cSrcW.c[c]);
+        diffNoBias[c] = diffBias[c] - bias[c];
+      }
+      // cv::Vec::dot accumulates left to right from 0
+      float d0 = 0, d1 = 0;
+      for (int c = 0; c < 3; ++c) {
+        d0 += diffBias[c] * diffBias[c];
+        d1 += diffNoBias[c] * diffNoBias[c];
+      }
+      ssd.first += d0;
+      ssd.second += d1;
+    }
+  }
+  const float maxDepth = 65535.0f;
+  const float scaleFactor = 1.0f / (maxDepth * maxDepth);
+  ssd.first *= scaleFactor;
+  ssd.second *= scaleFactor;
+  return ssd;
+}
+
+// ---- per-level state: PyramidLevel.h:24-131 ----
+struct Params {
+  int32_t level, numLevels;
+  int32_t width, height;
+  int32_t widthFull, heightFull;
+  float minDepthM, maxDepthM;
+  float varNoiseFloorFull, varHighThresh;
+  int32_t randomProposals, pingPongIterations, mismatchesStartLevel;
+  int32_t doBilateral, doMedian, useFgMasks, partialCoverage;
+  int32_t threads;
+};
+
+struct Counters {
+  uint64_t nCost = 0, nPair = 0;
+};
+
+struct Level {
+  Params p;
+  Rig rigSrc, rigDst; // normalised
+  std::vector<int> dst2src;
+  int S, D, W, H;
+  float varNoiseFloor, varHighThresh;
+  bool hasFg;
+
+  std::vector<Img<Px3w>> srcColor;
+  std::vector<Img<float>> srcVariance;
+  std::vector<Img<uint8_t>> srcFg;
+
+  std::vector<Img<float>> disparity, cost, confidence, bgDisp;
+  std::vector<Img<uint8_t>> fovMask, mismatchMask;
+
+  // proj[d*S+s]
+  std::vector<Img<Px2f>> projWarp, projWarpInv;
+  std::vector<Img<Px3w>> projColor, projColorBias;
+
+  std::atomic<uint64_t> nCost{0}, nPair{0};
+  std::atomic<int> insufficientCoverage{0};
+  std::atomic<int> coverageCheckFailed{0};
+
+  int idx(int d, int s) const {
+    return d * S + s;
+  }
+  const Img<Px3w>& dstProjColor(int d) const {
+    return projColor[idx(d, dst2src[d])];
+  }
+  const Img<Px3w>& dstProjColorBias(int d) const {
+    return projColorBias[idx(d, dst2src[d])];
+  }
+  const Img<float>& dstVariance(int d) const {
+    return srcVariance[dst2src[d]];
+  }
+  const Img<uint8_t>& dstFg(int d) const {
+    return srcFg[dst2src[d]];
+  }
+  void flush(const Counters& c) {
+    nCost += c.nCost;
+    nPair += c.nPair;
+  }
+};
+
+// ---- DerpUtil.cpp:214-237 + PyramidLevel.h:232-247 ----
+static Img<float> computeImageVariance(const Img<Px3w>& image) {
+  const int w = image.w, h = image.h;
+  Img<Px3f> imageF(w, h), sq(w, h), mean, meanSq;
+  const float scale = 1.0f / 65535.0f; // CvUtil.h:196-207 convertTo(CV_32F, 1/65535)
+  for (size_t i = 0; i < image.d.size(); ++i) {
+    for (int c = 0; c < 3; ++c) {
+      const float v = image.d[i].c[c] * scale;
+      imageF.d[i].c[c] = v;
+      sq.d[i].c[c] = v * v;
+    }
+  }
+  blur3x3F32C3(imageF, mean);
+  blur3x3F32C3(sq, meanSq);
+  Img<float> var(w, h);
+  for (size_t i = 0; i < var.d.size(); ++i) {
+    float v[3];
+    for (int c = 0; c < 3; ++c) {
+      v[c] = meanSq.d[i].c[c] - mean.d[i].c[c] * mean.d[i].c[c];
+    }
+    // varChannels[0]*w[2] + varChannels[1]*w[1] + varChannels[2]*w[0]   (BGR order)
+    const float t = v[0] * kRgbWeights[2] + v[1] * kRgbWeights[1];
+    var.d[i] = t * 1.0f + v[2] * kRgbWeights[0];
+  }
+  return var;
+}
+
+// ---- DerpUtil.cpp:239-276 ----
+static Img<uint8_t> generateFovMask(const Camera& cam, int w, int h) {
+  Img<uint8_t> m(w, h);
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      V2 p = {x + 0.5, y + 0.5};
+      if (cam.isNormalized()) {
+        p = {p.x / w, p.y / h};
+      }
+      m.at(y, x) = !cam.isOutsideImageCircle(p);
+    }
+  }
+  return m;
+}
+
+// ---- ImageUtil.cpp:142-167 ----
+static Img<Px2f> computeWarpDstToSrc(const Camera& dst, const Camera& src) {
+  const int dw = (int)dst.resolution.x, dh = (int)dst.resolution.y;
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  Img<Px2f> warp(dw, dh, Px2f{{nan, nan}});
+  if (dst.id == src.id) {
+    return warp;
+  }
+  for (int y = 0; y < dh; ++y) {
+    for (int x = 0; x < dw; ++x) {
+      const V2 dstPixel = {x + 0.5, y + 0.5};
+      if (dst.isOutsideImageCircle(dstPixel)) {
+        continue;
+      }
+      const V3 rig = dst.rigNearInfinity(dstPixel);
+      V2 srcPixel;
+      if (!src.sees(rig, srcPixel)) {
+        continue;
+      }
+      warp.at(y, x) = Px2f{{float(srcPixel.x - 0.5f), float(srcPixel.y - 0.5f)}};
+    }
+  }
+  return warp;
+}
+
+// ---- Derp.cpp:955-976 ----
+static void precomputeProjections(Level& L) {
+  const int n = L.D * L.S;
+  L.projWarp.assign(n, Img<Px2f>());
+  L.projWarpInv.assign(n, Img<Px2f>());
+  parallelFor(0, n, L.p.threads, [&](int i) {
+    const int d = i / L.S, s = i % L.S;
+    const Camera camDst = L.rigDst[d].rescale({double(L.W), double(L.H)});
+    const Camera camSrc = L.rigSrc[s].rescale({double(L.W), double(L.H)});
+    L.projWarp[i] = computeWarpDstToSrc(camSrc, camDst);
+    L.projWarpInv[i] = computeWarpDstToSrc(camDst, camSrc);
+  });
+}
+
+// ---- Derp.cpp:978-1003 ----
+static void reprojectColors(Level& L) {
+  const int n = L.D * L.S;
+  L.projColor.assign(n, Img<Px3w>());
+  L.projColorBias.assign(n, Img<Px3w>());
+  parallelFor(0, n, L.p.threads, [&](int i) {
+    const int d = i / L.S, s = i % L.S;
+    if (s == L.dst2src[d]) {
+      L.projColor[i] = L.srcColor[s];
+    } else {
+      remapCubicU16C3(L.srcColor[s], L.projWarpInv[i], L.projColor[i]);
+    }
+    blur3x3U16C3(L.projColor[i], L.projColorBias[i]);
+  });
+}
+
+// ---- Derp.cpp:104-226 ----
+static inline std::pair<float, float>
+computeCost(const Level& L, const int dstIdx, const float disparity, const int x, const int y, Counters& cnt) {
+  ++cnt.nCost;
+  const Img<Px3w>& dstColor = L.dstProjColor(dstIdx);
+  const Camera& camDst = L.rigDst[dstIdx];
+  const V3 pWorld = dstToWorldPoint(camDst, x, y, disparity, dstColor.w, dstColor.h);
+
+  using SSDPair = std::pair<float, float>;
+  SSDPair SSDs[64];
+  int ssdCount = 0;
+  const Img<Px3w>& dstColorBias = L.dstProjColorBias(dstIdx);
+  for (int srcIdx = 0; srcIdx < L.S; ++srcIdx) {
+    if (srcIdx == L.dst2src[dstIdx]) {
+      continue;
+    }
+    const Camera& camSrc = L.rigSrc[srcIdx];
+    V2 pSrc;
+    if (!worldToSrcPoint(pSrc, pWorld, camSrc, L.W, L.H)) {
+      continue;
+    }
+    const Img<Px2f>& dstProjWarp = L.projWarp[L.idx(dstIdx, srcIdx)];
+    const Px2f pDstSrc = getPixelBilinear(dstProjWarp, float(pSrc.x), float(pSrc.y));
+    const float xDstSrc = pDstSrc.c[0] + 0.5;
+    const float yDstSrc = pDstSrc.c[1] + 0.5;
+    if (std::isnan(xDstSrc) || std::isnan(yDstSrc)) {
+      continue;
+    }
+    ++cnt.nPair;
+    const Img<Px3w>& dstSrcColorBias = L.projColorBias[L.idx(dstIdx, srcIdx)];
+    const Px3w dstSrcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc);
+    const Px3w& dstBias = dstColorBias.at(y, x);
+    const Img<Px3w>& dstSrcColor = L.projColor[L.idx(dstIdx, srcIdx)];
+    SSDs[ssdCount] = computeSSD(
+        dstColor, x, y, dstBias, dstSrcColor, xDstSrc, yDstSrc, dstSrcBias, kSearchWindowRadius);
+    ++ssdCount;
+  }
+
+  int keep = kMinOverlappingCams - 1;
+  if (ssdCount < keep) {
+    return {FLT_MAX, 0.0f};
+  }
+  keep = std::max<int>(keep, ssdCount - 2);
+  std::nth_element(SSDs, SSDs + keep, SSDs + ssdCount);
+  float cost = 0;
+  for (int i = 0; i < keep; ++i) {
+    cost += SSDs[i].second;
+  }
+  cost /= keep;
+  const float trustCoef = 1.0f / keep;
+  const float dstVariance = L.dstVariance(dstIdx).at(y, x);
+  const float confidence = std::max(dstVariance, kMinVar);
+  const float costFinal = cost * trustCoef / confidence;
+  return {costFinal, confidence};
+}
+
+// ImageUtil.cpp:100-107
+static inline double
+probeDisparity(const int probe, const int probeCount, const double minD, const double maxD) {
+  const double fraction = double(probe) / double(probeCount - 1);
+  return fraction * minD + (1 - fraction) * maxD;
+}
+
+// ---- Derp.cpp:230-382 ----
+static void computeBruteForceDisparity(Level& L, const int dstIdx) {
+  Img<float>& dstDisparity = L.disparity[dstIdx];
+  Img<float>& dstCosts = L.cost[dstIdx];
+  Img<float>& dstConfidences = L.confidence[dstIdx];
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+
+  std::vector<float> disparities(kNumDepths);
+  const float minDisparity = 1.0f / L.p.maxDepthM;
+  const float maxDisparity = 1.0f / L.p.minDepthM;
+  for (int i = 0; i < kNumDepths; ++i) {
+    disparities[i] = probeDisparity(i, kNumDepths, minDisparity, maxDisparity);
+  }
+  std::vector<Img<float>> costs(kNumDepths), confidences(kNumDepths);
+  const Img<uint8_t>& fov = L.fovMask[dstIdx];
+  const Img<uint8_t>& fg = L.dstFg(dstIdx);
+  parallelFor(0, kNumDepths, L.p.threads, [&](int i) {
+    Counters cnt;
+    costs[i] = Img<float>(L.W, L.H, nan);
+    confidences[i] = Img<float>(L.W, L.H, nan);
+    const float disparity = disparities[i];
+    const int radius = kSearchWindowRadius;
+    for (int y = radius; y < L.H - radius; ++y) {
+      for (int x = radius; x < L.W - radius; ++x) {
+        const bool closer = L.hasFg ? (L.bgDisp[dstIdx].at(y, x) < disparity) : true;
+        const bool ignore = !fov.at(y, x) || !fg.at(y, x) || !closer;
+        if (ignore) {
+          costs[i].at(y, x) = nan;
+          confidences[i].at(y, x) = nan;
+        } else {
+          std::tie(costs[i].at(y, x), confidences[i].at(y, x)) =
+              computeCost(L, dstIdx, disparity, x, y, cnt);
+        }
+      }
+    }
+    L.flush(cnt);
+  });
+
+  const int margin = kSearchWindowRadius;
+  for (int y = margin; y < L.H - margin; ++y) {
+    for (int x = margin; x < L.W - margin; ++x) {
+      if (!fov.at(y, x)) {
+        dstDisparity.at(y, x) = nan;
+        continue;
+      }
+      if (!fg.at(y, x)) {
+        dstDisparity.at(y, x) = L.bgDisp[dstIdx].at(y, x);
+        continue;
+      }
+      float minCost = FLT_MAX;
+      float minCostConfidence = 0;
+      int best = -1;
+      for (int i = 0; i < kNumDepths; ++i) {
+        const float c = costs[i].at(y, x);
+        if (c < minCost) {
+          minCost = c;
+          minCostConfidence = confidences[i].at(y, x);
+          best = i;
+        }
+      }
+      if (best == -1) {
+        // reference: CHECK(partialCoverage || useForegroundMasks) then LOG(WARNING)
+        if (!(L.p.partialCoverage || L.p.useFgMasks)) {
+          L.coverageCheckFailed++;
+        }
+        L.insufficientCoverage++;
+        dstDisparity.at(y, x) = minDisparity;
+      } else {
+        dstDisparity.at(y, x) = disparities[best];
+      }
+      dstCosts.at(y, x) = minCost;
+      dstConfidences.at(y, x) = minCostConfidence;
+    }
+  }
+  if (margin > 0) {
+    for (int y = 0; y < L.H; ++y) {
+      for (int x = 0; x < L.W; ++x) {
+        if (x < margin || x >= L.W - margin || y < margin || y >= L.H - margin) {
+          if (!fg.at(y, x)) {
+            dstDisparity.at(y, x) = L.bgDisp[dstIdx].at(y, x);
+            continue;
+          }
+          const int yy = clampT(y, margin, L.H - margin - 1);
+          const int xx = clampT(x, margin, L.W - margin - 1);
+          dstDisparity.at(y, x) = dstDisparity.at(yy, xx);
+          dstCosts.at(y, x) = dstCosts.at(yy, xx);
+          dstConfidences.at(y, x) = dstConfidences.at(yy, xx);
+        }
+      }
+    }
+  }
+}
+
+// ---- Derp.cpp:750-824 ----
+static void randomProposalRow(Level& L, const int dstIdx, const int y, Counters& cnt) {
+  std::default_random_engine engine;
+  engine.seed(y * L.p.level);
+  Img<float>& dstDisparity = L.disparity[dstIdx];
+  Img<float>& dstCosts = L.cost[dstIdx];
+  Img<float>& dstConfidence = L.confidence[dstIdx];
+  const Img<float>& variance = L.dstVariance(dstIdx);
+  const int numProposals = L.p.randomProposals;
+  for (int x = kSearchWindowRadius; x < L.W - kSearchWindowRadius; ++x) {
+    if (!L.fovMask[dstIdx].at(y, x)) {
+      continue;
+    }
+    float currDisp = dstDisparity.at(y, x);
+    if (!L.dstFg(dstIdx).at(y, x)) {
+      dstDisparity.at(y, x) = L.bgDisp[dstIdx].at(y, x);
+      continue;
+    }
+    const float varHighDev = kRandomPropHighVarDeviation * L.varHighThresh;
+    const float varHighThresh = std::max(varHighDev, L.varNoiseFloor);
+    if (variance.at(y, x) < varHighThresh) {
+      continue;
+    }
+    float currCost, currConfidence;
+    std::tie(currCost, currConfidence) = computeCost(L, dstIdx, currDisp, x, y, cnt);
+    const float costThresh = std::fmin(0.5f * currCost, kRandomPropMaxCost);
+    const float minDisp = L.hasFg ? L.bgDisp[dstIdx].at(y, x) : (1.0f / L.p.maxDepthM);
+    const float maxDisp = 1.0f / L.p.minDepthM;
+    float amplitude = (maxDisp - minDisp) / 2.0f;
+    for (int i = 0; i < numProposals; ++i) {
+      float propDisp = std::uniform_real_distribution<float>(
+          std::max(float(minDisp), currDisp - amplitude),
+          std::min(float(maxDisp), currDisp + amplitude))(engine);
+      float propCost, propConfidence;
+      std::tie(propCost, propConfidence) = computeCost(L, dstIdx, propDisp, x, y, cnt);
+      if (propCost < currCost && propCost < costThresh) {
+        currCost = propCost;
+        currDisp = propDisp;
+        currConfidence = propConfidence;
+        amplitude /= 2.0f;
+      }
+    }
+    dstDisparity.at(y, x) = currDisp;
+    dstCosts.at(y, x) = currCost;
+    dstConfidence.at(y, x) = currConfidence;
+  }
+}
+
+// Derp.cpp:844-873
+static void randomProposals(Level& L) {
+  if (L.p.randomProposals <= 0 || L.p.level == L.p.numLevels - 1) {
+    return;
+  }
+  for (int d = 0; d < L.D; ++d) {
+    parallelFor(kSearchWindowRadius, L.H - kSearchWindowRadius, L.p.threads, [&](int y) {
+      Counters cnt;
+      randomProposalRow(L, d, y, cnt);
+      L.flush(cnt);
+    });
+  }
+}
+
+// ---- Derp.cpp:403-551 ----
+static void pingPong(Level& L, std::vector<float>* changedPctOut) {
+  if (L.p.level == L.p.numLevels - 1) {
+    return;
+  }
+  for (int dstIdx = 0; dstIdx < L.D; ++dstIdx) {
+    Img<float>& disp = L.disparity[dstIdx];
+    Img<float>& costs = L.cost[dstIdx];
+    Img<float> dispRes = disp;
+    Img<float> costsRes(L.W, L.H, INFINITY);
+    Img<float> confidencesRes(L.W, L.H, 0.f);
+    Img<uint8_t> changed(L.W, L.H, 1);
+    const Img<uint8_t>& maskFov = L.fovMask[dstIdx];
+    const Img<float>& variance = L.dstVariance(dstIdx);
+    const Img<float>& confidences = L.confidence[dstIdx];
+    for (int it = 1; it <= L.p.pingPongIterations; ++it) {
+      const int radius = kSearchWindowRadius;
+      parallelFor(radius, L.H - radius, L.p.threads, [&](int y) {
+        Counters cnt;
+        for (int x = radius; x < L.W - radius; ++x) {
+          if (!maskFov.at(y, x)) {
+            continue;
+          }
+          if (!L.dstFg(dstIdx).at(y, x)) {
+            dispRes.at(y, x) = L.bgDisp[dstIdx].at(y, x);
+            continue;
+          }
+          if (variance.at(y, x) < L.varNoiseFloor) {
+            continue;
+          }
+          float bestCost = INFINITY;
+          float bestDisparity = disp.at(y, x);
+          float bestConfidence = confidences.at(y, x);
+          const float backgroundDisparity = L.hasFg ? L.bgDisp[dstIdx].at(y, x) : 0;
+          for (int k = 0; k < 9; ++k) {
+            const int xx = clampT(x + kCandidateTemplate[k][0], 0, L.W - 1);
+            const int yy = clampT(y + kCandidateTemplate[k][1], 0, L.H - 1);
+            if (maskFov.at(yy, xx)) {
+              const float d = disp.at(yy, xx);
+              if (d >= backgroundDisparity && changed.at(yy, xx)) {
+                const auto cv = computeCost(L, dstIdx, d, x, y, cnt);
+                if (cv.first < bestCost) {
+                  bestCost = cv.first;
+                  bestDisparity = d;
+                  bestConfidence = cv.second;
+                }
+              }
+            }
+          }
+          dispRes.at(y, x) = bestDisparity;
+          costsRes.at(y, x) = bestCost;
+          confidencesRes.at(y, x) = bestConfidence;
+        }
+        L.flush(cnt);
+      });
+      // changed = disp != dispRes (NaN != NaN is true, as cv::compare CMP_NE)
+      int count = 0, countFov = 0;
+      for (size_t i = 0; i < disp.d.size(); ++i) {
+        changed.d[i] = disp.d[i] != dispRes.d[i];
+        count += changed.d[i];
+        countFov += maskFov.d[i] != 0;
+      }
+      disp = dispRes;
+      costs = costsRes;
+      if (changedPctOut) {
+        changedPctOut->push_back(100.0f * count / countFov);
+      }
+    }
+  }
+}
+
+// ---- TemporalBilateralFilter.h:39-124, TGuide = Vec3w ----
+static Img<float> generalizedJointBilateralFilterU16(
+    const Img<float>& image,
+    const Img<Px3w>& guide,
+    const Img<Px3w>& neighborGuide,
+    const Img<uint8_t>& mask,
+    const int radius,
+    const float sigma,
+    const float weight0,
+    const float weight1,
+    const float weight2,
+    const int threads) {
+  Img<float> dest(image.w, image.h);
+  parallelFor(0, image.h, threads, [&](int y) {
+    for (int x = 0; x < image.w; ++x) {
+      if (!mask.at(y, x)) {
+        dest.at(y, x) = image.at(y, x);
+        continue;
+      }
+      const Px3w guideColor = guide.at(y, x);
+      float sumWeight = 0.0f;
+      float weightedAvg = 0.0f;
+      const float guideFactor = 1 / 65535.0f;
+      const float neighborFactor = 1 / 65535.0f;
+      for (int v = -radius; v <= radius; ++v) {
+        for (int u = -radius; u <= radius; ++u) {
+          const int sampleX = clampT(x + u, 0, image.w - 1);
+          const int sampleY = clampT(y + v, 0, image.h - 1);
+          if (!mask.at(sampleY, sampleX)) {
+            continue;
+          }
+          const Px3w& nb = neighborGuide.at(sampleY, sampleX);
+          auto sq = [](float a) { return a * a; };
+          const float colorDiffSq =
+              weight0 * sq((guideColor.c[0] * guideFactor) - (nb.c[0] * neighborFactor)) +
+              weight1 * sq((guideColor.c[1] * guideFactor) - (nb.c[1] * neighborFactor)) +
+              weight2 * sq((guideColor.c[2] * guideFactor) - (nb.c[2] * neighborFactor));
+          const float weight = expf((-colorDiffSq / 3.0f) / (2.0f * (sigma * sigma)));
+          sumWeight += weight;
+          weightedAvg += weight * image.at(sampleY, sampleX);
+        }
+      }
+      if (sumWeight != 0.0f) {
+        weightedAvg /= sumWeight;
+        dest.at(y, x) = weightedAvg;
+      } else {
+        dest.at(y, x) = image.at(y, x);
+      }
+    }
+  });
+  return dest;
+}
+
+// TGuide = Vec3f (UpsampleDisparity.cpp:109-128): maxPixelValue(CV_32F) = 1
+static Img<float> generalizedJointBilateralFilterF32(
+    const Img<float>& image,
+    const Img<Px3f>& guide,
+    const Img<uint8_t>& mask,
+    const int radius,
+    const float sigma,
+    const float weight0,
+    const float weight1,
+    const float weight2,
+    const int threads) {
+  Img<float> dest(image.w, image.h);
+  parallelFor(0, image.h, threads, [&](int y) {
+    for (int x = 0; x < image.w; ++x) {
+      if (!mask.at(y, x)) {
+        dest.at(y, x) = image.at(y, x);
+        continue;
+      }
+      const Px3f guideColor = guide.at(y, x);
+      float sumWeight = 0.0f;
+      float weightedAvg = 0.0f;
+      const float factor = 1 / 1.0f;
+      for (int v = -radius; v <= radius; ++v) {
+        for (int u = -radius; u <= radius; ++u) {
+          const int sampleX = clampT(x + u, 0, image.w - 1);
+          const int sampleY = clampT(y + v, 0, image.h - 1);
+          if (!mask.at(sampleY, sampleX)) {
+            continue;
+          }
+          const Px3f& nb = guide.at(sampleY, sampleX);
+          auto sq = [](float a) { return a * a; };
+          const float colorDiffSq = weight0 * sq((guideColor.c[0] * factor) - (nb.c[0] * factor)) +
+              weight1 * sq((guideColor.c[1] * factor) - (nb.c[1] * factor)) +
+              weight2 * sq((guideColor.c[2] * factor) - (nb.c[2] * factor));
+          const float weight = expf((-colorDiffSq / 3.0f) / (2.0f * (sigma * sigma)));
+          sumWeight += weight;
+          weightedAvg += weight * image.at(sampleY, sampleX);
+        }
+      }
+      if (sumWeight != 0.0f) {
+        weightedAvg /= sumWeight;
+        dest.at(y, x) = weightedAvg;
+      } else {
+        dest.at(y, x) = image.at(y, x);
+      }
+    }
+  });
+  return dest;
+}
+
+static int bilateralRadius(int level) { // Derp.cpp:876-878
+  const float scale = std::pow(kLevelScale, level);
+  return std::max(std::ceil(kBilateralSpaceRadiusMax * scale), float(kBilateralSpaceRadiusMin));
+}
+
+// ---- Derp.cpp:875-902 ----
+static void bilateralFilter(Level& L) {
+  const int spaceRadius = bilateralRadius(L.p.level);
+  for (int d = 0; d < L.D; ++d) {
+    Img<float>& disparity = L.disparity[d];
+    const Img<Px3w>& color = L.srcColor[L.dst2src[d]];
+    Img<uint8_t> mask(L.W, L.H);
+    for (size_t i = 0; i < mask.d.size(); ++i) {
+      mask.d[i] = L.fovMask[d].d[i] & L.dstFg(d).d[i];
+    }
+    const Img<float> filtered = generalizedJointBilateralFilterU16(
+        disparity,
+        color,
+        color,
+        mask,
+        spaceRadius,
+        kBilateralSigma,
+        kBilateralWeightB,
+        kBilateralWeightG,
+        kBilateralWeightR,
+        L.p.threads);
+    for (size_t i = 0; i < mask.d.size(); ++i) {
+      if (L.dstFg(d).d[i]) {
+        disparity.d[i] = filtered.d[i];
+      }
+    }
+  }
+}
+
+// ---- CvUtil.h:336-385 ----
+static Img<float> maskedMedianBlur(
+    const Img<float>& mat, const Img<float>& background, const Img<uint8_t>& mask, const int radius) {
+  Img<float> blurred(mat.w, mat.h, 0.0f);
+  for (int y = 0; y < mat.h; ++y) {
+    for (int x = 0; x < mat.w; ++x) {
+      std::vector<float> values;
+      if (!mask.at(y, x)) {
+        if (!background.empty()) {
+          blurred.at(y, x) = background.at(y, x);
+        }
+        continue;
+      }
+      for (int yy = y - radius; yy <= y + radius; ++yy) {
+        for (int xx = x - radius; xx <= x + radius; ++xx) {
+          if (0 > yy || yy >= mat.h || 0 > xx || xx >= mat.w) {
+            continue;
+          }
+          if (!mask.at(yy, xx)) {
+            continue;
+          }
+          if (std::isnan(mat.at(yy, xx)) || mat.at(yy, xx) == 0) {
+            continue;
+          }
+          values.push_back(mat.at(yy, xx));
+        }
+      }
+      if (!values.empty()) {
+        const size_t n = values.size() / 2;
+        std::partial_sort(values.begin(), values.begin() + n + 1, values.end());
+        if (values.size() % 2 == 1) {
+          blurred.at(y, x) = values[n];
+        } else {
+          blurred.at(y, x) = (values[n - 1] + values[n]) / 2.0;
+        }
+      }
+    }
+  }
+  return blurred;
+}
+
+// ---- Derp.cpp:904-920 ----
+static void medianFilter(Level& L) {
+  parallelFor(0, L.D, L.p.threads, [&](int d) {
+    Img<uint8_t> mask(L.W, L.H);
+    for (size_t i = 0; i < mask.d.size(); ++i) {
+      mask.d[i] = L.fovMask[d].d[i] & L.dstFg(d).d[i];
+    }
+    L.disparity[d] = maskedMedianBlur(L.disparity[d], L.bgDisp[d], mask, kMedianFilterRadius);
+  });
+}
+
+// ---- Derp.cpp:940-951 ----
+static void maskFov(Level& L) {
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  for (int d = 0; d < L.D; ++d) {
+    for (size_t i = 0; i < L.disparity[d].d.size(); ++i) {
+      if (!L.fovMask[d].d[i]) {
+        L.disparity[d].d[i] = nan;
+      }
+    }
+  }
+}
+
+// ---- UpsampleDisparityLib.cpp:27-147 ----
+static std::vector<std::pair<int, int>> spiral(const int w) {
+  int x = 0, y = 0, dx = 0, dy = -1, t = w;
+  const int samples = t * t;
+  std::vector<std::pair<int, int>> locs;
+  for (int i = 0; i < samples; ++i) {
+    const bool isValidX = (-w / 2 <= x) && (x <= w / 2);
+    const bool isValidY = (-w / 2 <= y) && (y <= w / 2);
+    if (isValidX && isValidY) {
+      locs.emplace_back(x, y);
+    }
+    const bool isCorner = x == y;
+    const bool isEdgeLeftX = (x < 0) && (x == -y);
+    const bool isEdgeRightX = (x > 0) && (x == 1 - y);
+    if (isCorner || isEdgeLeftX || isEdgeRightX) {
+      t = dx;
+      dx = -dy;
+      dy = t;
+    }
+    x += dx;
+    y += dy;
+  }
+  return locs;
+}
+
+static Img<float> replaceNans(
+    const Img<float>& dispUp, const Img<float>& bgDispUp, const Img<uint8_t>& maskUp, const int radius) {
+  Img<float> dispOut = dispUp;
+  const auto spiralLocs = spiral(radius * 2 + 1);
+  for (int py = 0; py < dispUp.h; ++py) {
+    for (int px = 0; px < dispUp.w; ++px) {
+      // maskNan = maskUp with (dispUp > 0) cleared: true = NaN (or <= 0) inside mask
+      if (!maskUp.at(py, px) || dispUp.at(py, px) > 0) {
+        continue;
+      }
+      for (const auto& loc : spiralLocs) {
+        const int xx = clampT(px + loc.first, 0, dispUp.w - 1);
+        const int yy = clampT(py + loc.second, 0, dispUp.h - 1);
+        const float d = dispUp.at(yy, xx);
+        if (d > 0) {
+          dispOut.at(py, px) = d;
+          break;
+        }
+      }
+    }
+  }
+  for (size_t i = 0; i < dispOut.d.size(); ++i) {
+    if (std::isnan(dispOut.d[i]) || dispOut.d[i] == 0) {
+      dispOut.d[i] = bgDispUp.d[i];
+    }
+  }
+  return dispOut;
+}
+
+static int getUpsampleRadius(int w, int wUp) { // UpsampleDisparityLib.cpp:93-96
+  const float scale = float(wUp) / float(w);
+  return scale * scale + 1;
+}
+
+static Img<float> upsampleDisparity(
+    const Img<float>& disp,
+    const Img<float>& bgDispUp,
+    const Img<uint8_t>& mask, // fov & fg at coarse size
+    const Img<uint8_t>& maskUp, // fov & fg at up size
+    const int wUp,
+    const int hUp,
+    const bool useForegroundMasks) {
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  Img<float> dispUp;
+  if (useForegroundMasks) {
+    const int radius = getUpsampleRadius(mask.w, wUp);
+    Img<float> dispSmallMasked = disp;
+    for (size_t i = 0; i < disp.d.size(); ++i) {
+      if (mask.d[i] == 0) {
+        dispSmallMasked.d[i] = nan;
+      }
+    }
+    Img<float> dispUpMasked;
+    resizeNearest(dispSmallMasked, wUp, hUp, dispUpMasked);
+    for (size_t i = 0; i < dispUpMasked.d.size(); ++i) {
+      if (maskUp.d[i] == 0) {
+        dispUpMasked.d[i] = nan;
+      }
+    }
+    dispUp = replaceNans(dispUpMasked, bgDispUp, maskUp, radius);
+  } else {
+    const float minDisp = 1e-4;
+    Img<float> dispSmallMasked = disp;
+    for (size_t i = 0; i < disp.d.size(); ++i) {
+      if (disp.d[i] != disp.d[i]) {
+        dispSmallMasked.d[i] = minDisp;
+      }
+    }
+    resizeLanczos4F32(dispSmallMasked, wUp, hUp, dispUp);
+  }
+  return dispUp;
+}
+
+// ---- TemporalBilateralFilter.h:126-172 (guide = Vec3w) ----
+static Img<float> temporalJointBilateralFilter(
+    const std::vector<const Px3w*>& guides,
+    const std::vector<const float*>& images,
+    const std::vector<const uint8_t*>& masks,
+    const int w,
+    const int h,
+    const int frameOffset,
+    const float sigma,
+    const int spatialRadius,
+    const float weight0,
+    const float weight1,
+    const float weight2,
+    const int threads) {
+  Img<float> result(w, h);
+  const float maxImageValue = 65535.0f;
+  const int nT = (int)guides.size();
+  parallelFor(0, h, threads, [&](int y) {
+    for (int x = 0; x < w; ++x) {
+      const size_t c = size_t(y) * w + x;
+      if (!masks[frameOffset][c]) {
+        result.at(y, x) = images[frameOffset][c];
+        continue;
+      }
+      float weightedSumPix = 0.0f;
+      float sumWeight = 0.0f;
+      const Px3w referenceColor = guides[frameOffset][c];
+      for (int t = 0; t < nT; ++t) {
+        for (int u = -spatialRadius; u <= spatialRadius; ++u) {
+          for (int v = -spatialRadius; v <= spatialRadius; ++v) {
+            const int sampleX = clampT(x + u, 0, w - 1);
+            const int sampleY = clampT(y + v, 0, h - 1);
+            const size_t si = size_t(sampleY) * w + sampleX;
+            if (!masks[t][si]) {
+              continue;
+            }
+            const Px3w sampleColor = guides[t][si];
+            auto sq = [](float a) { return a * a; };
+            // ushort - ushort promotes to int (exact, signed), then / float
+            const float weightedDiff =
+                weight0 * sq((referenceColor.c[0] - sampleColor.c[0]) / maxImageValue) +
+                weight1 * sq((referenceColor.c[1] - sampleColor.c[1]) / maxImageValue) +
+                weight2 * sq((referenceColor.c[2] - sampleColor.c[2]) / maxImageValue);
+            const float weight = expf(-weightedDiff / (sigma * sigma));
+            weightedSumPix += images[t][c] * weight; // centre pixel of frame t (TemporalBilateralFilter.h:165)
+            sumWeight += weight;
+          }
+        }
+      }
+      result.at(y, x) = (weightedSumPix / sumWeight);
+    }
+  });
+  return result;
+}
+
+} // namespace oracle
+
+// =====================================================================
+// C interface (ctypes). All images row-major; colour = interleaved BGR u16.
+// =====================================================================
+using namespace oracle;
+
+extern "C" {
+
+struct OracleRig {
+  Rig cams;
+};
+
+OracleRig* oracle_rig_create(const CameraJson* cams, int n) {
+  OracleRig* r = new OracleRig;
+  for (int i = 0; i < n; ++i) {
+    r->cams.emplace_back(cams[i]);
+  }
+  return r;
+}
+void oracle_rig_destroy(OracleRig* r) {
+  delete r;
+}
+int oracle_rig_size(const OracleRig* r) {
+  return (int)r->cams.size();
+}
+int oracle_cam_valid(const OracleRig* r, int i) {
+  return r->cams[i].valid;
+}
+void oracle_rig_normalize(OracleRig* r) { // Camera.cpp:236-242
+  for (Camera& c : r->cams) {
+    if (!c.isNormalized()) {
+      c.normalize();
+    }
+  }
+}
+void oracle_cam_rescale(OracleRig* r, int i, double w, double h) {
+  r->cams[i] = r->cams[i].rescale({w, h});
+}
+// state dump: position[3], R[9], resolution[2], principal[2], focal[2], dist[3], distMax, cosFov
+void oracle_cam_get(const OracleRig* r, int i, double* out23) {
+  const Camera& c = r->cams[i];
+  double* o = out23;
+  *o++ = c.position.x;
+  *o++ = c.position.y;
+  *o++ = c.position.z;
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b < 3; ++b) {
+      *o++ = c.R[a][b];
+    }
+  }
+  *o++ = c.resolution.x;
+  *o++ = c.resolution.y;
+  *o++ = c.principal.x;
+  *o++ = c.principal.y;
+  *o++ = c.focal.x;
+  *o++ = c.focal.y;
+  *o++ = c.dist[0];
+  *o++ = c.dist[1];
+  *o++ = c.dist[2];
+  *o++ = c.distMax;
+  *o++ = c.cosFov;
+}
+void oracle_cam_set_fov(OracleRig* r, int i, double fov, int setDefault) {
+  if (setDefault) {
+    r->cams[i].setDefaultFov();
+  } else {
+    r->cams[i].setFov(fov);
+  }
+}
+double oracle_cam_get_fov(const OracleRig* r, int i) {
+  return r->cams[i].getFov();
+}
+void oracle_cam_set_distortion(OracleRig* r, int i, const double* d3, int setDefault) {
+  if (setDefault) {
+    r->cams[i].setDefaultDistortion();
+  } else {
+    r->cams[i].setDistortion(d3);
+  }
+}
+void oracle_cam_pixel(const OracleRig* r, int i, const double* xyz, int n, double* out) {
+  for (int k = 0; k < n; ++k) {
+    const V2 p = r->cams[i].pixel({xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]});
+    out[2 * k] = p.x;
+    out[2 * k + 1] = p.y;
+  }
+}
+void oracle_cam_rig(const OracleRig* r, int i, const double* pix, const double* depth, int n, double* out) {
+  for (int k = 0; k < n; ++k) {
+    const V3 p = r->cams[i].rig({pix[2 * k], pix[2 * k + 1]}, depth[k]);
+    out[3 * k] = p.x;
+    out[3 * k + 1] = p.y;
+    out[3 * k + 2] = p.z;
+  }
+}
+void oracle_cam_sees(const OracleRig* r, int i, const double* xyz, int n, uint8_t* sees, double* pix) {
+  for (int k = 0; k < n; ++k) {
+    V2 p = {NAN, NAN};
+    sees[k] = r->cams[i].sees({xyz[3 * k], xyz[3 * k + 1], xyz[3 * k + 2]}, p);
+    pix[2 * k] = p.x;
+    pix[2 * k + 1] = p.y;
+  }
+}
+int oracle_cam_is_outside_image_circle(const OracleRig* r, int i, double px, double py) {
+  return r->cams[i].isOutsideImageCircle({px, py});
+}
+int oracle_cam_is_outside_sensor(const OracleRig* r, int i, double px, double py) {
+  return r->cams[i].isOutsideSensor({px, py});
+}
+int oracle_cam_is_behind(const OracleRig* r, int i, double x, double y, double z) {
+  return r->cams[i].isBehind({x, y, z});
+}
+double oracle_cam_distort(const OracleRig* r, int i, double v) {
+  return r->cams[i].distort(v);
+}
+double oracle_cam_undistort(const OracleRig* r, int i, double v) {
+  return r->cams[i].undistort(v);
+}
+
+// ---- level ----
+Level* oracle_level_create(
+    const OracleRig* rigSrc, const OracleRig* rigDst, const int* dst2src, const Params* p) {
+  Level* L = new Level;
+  L->p = *p;
+  L->rigSrc = rigSrc->cams;
+  L->rigDst = rigDst->cams;
+  L->S = (int)L->rigSrc.size();
+  L->D = (int)L->rigDst.size();
+  L->dst2src.assign(dst2src, dst2src + L->D);
+  L->W = p->width;
+  L->H = p->height;
+  L->hasFg = p->useFgMasks != 0;
+  // PyramidLevel.h:232-236 (note: width / heightFullSize — reference quirk kept)
+  const float scale = float(L->W) / p->heightFull;
+  const float scaleVar = scale * scale;
+  L->varNoiseFloor = std::max(p->varNoiseFloorFull * scaleVar, kMinVar);
+  L->varHighThresh = p->varHighThresh;
+  L->srcColor.resize(L->S);
+  L->srcVariance.resize(L->S);
+  L->srcFg.assign(L->S, Img<uint8_t>(L->W, L->H, 1));
+  L->disparity.assign(L->D, Img<float>(L->W, L->H, 0.f));
+  L->cost.assign(L->D, Img<float>(L->W, L->H, 0.f));
+  L->confidence.assign(L->D, Img<float>(L->W, L->H, 0.f));
+  L->mismatchMask.assign(L->D, Img<uint8_t>(L->W, L->H, 0));
+  L->bgDisp.assign(L->D, Img<float>());
+  L->fovMask.resize(L->D);
+  parallelFor(0, L->D, p->threads, [&](int d) {
+    L->fovMask[d] = generateFovMask(L->rigDst[d], L->W, L->H);
+  });
+  return L;
+}
+void oracle_level_destroy(Level* L) {
+  delete L;
+}
+void oracle_level_set_src(Level* L, int s, const uint16_t* bgr, const uint8_t* fg) {
+  L->srcColor[s] = Img<Px3w>(L->W, L->H);
+  memcpy(L->srcColor[s].d.data(), bgr, size_t(L->W) * L->H * 6);
+  if (fg) {
+    memcpy(L->srcFg[s].d.data(), fg, size_t(L->W) * L->H);
+  }
+  L->srcVariance[s] = computeImageVariance(L->srcColor[s]);
+}
+void oracle_level_set_dst(Level* L, int d, const float* disparity, const float* bg) {
+  if (disparity) {
+    memcpy(L->disparity[d].d.data(), disparity, size_t(L->W) * L->H * 4);
+  }
+  if (bg) {
+    L->bgDisp[d] = Img<float>(L->W, L->H);
+    memcpy(L->bgDisp[d].d.data(), bg, size_t(L->W) * L->H * 4);
+  }
+}
+void oracle_level_precompute_projections(Level* L) {
+  precomputeProjections(*L);
+}
+void oracle_level_reproject_colors(Level* L) {
+  reprojectColors(*L);
+}
+void oracle_level_brute_force(Level* L) { // Derp.cpp:826-842, 384-401
+  if (L->p.level == L->p.numLevels - 1) {
+    for (int d = 0; d < L->D; ++d) {
+      computeBruteForceDisparity(*L, d);
+    }
+  }
+}
+void oracle_level_random_proposals(Level* L) {
+  randomProposals(*L);
+}
+void oracle_level_ping_pong(Level* L) {
+  pingPong(*L, nullptr);
+}
+void oracle_level_bilateral(Level* L) {
+  bilateralFilter(*L);
+}
+void oracle_level_median(Level* L) {
+  medianFilter(*L);
+}
+void oracle_level_mask_fov(Level* L) {
+  maskFov(*L);
+}
+// Derp.cpp:1005-1034 (mismatch handling off: mismatches_start_level = -1 — not restated)
+void oracle_level_process(Level* L) {
+  reprojectColors(*L);
+  oracle_level_brute_force(L);
+  randomProposals(*L);
+  pingPong(*L, nullptr);
+  if (L->p.doBilateral) {
+    bilateralFilter(*L);
+  }
+  if (L->p.doMedian) {
+    medianFilter(*L);
+  }
+  maskFov(*L);
+}
+// cost of a caller-supplied disparity map at every interior pixel (test hook over computeCost)
+void oracle_level_cost_map(Level* L, int d, const float* disp, float* cost, float* conf) {
+  parallelFor(1, L->H - 1, L->p.threads, [&](int y) {
+    Counters cnt;
+    for (int x = 1; x < L->W - 1; ++x) {
+      const auto r = computeCost(*L, d, disp[size_t(y) * L->W + x], x, y, cnt);
+      cost[size_t(y) * L->W + x] = r.first;
+      conf[size_t(y) * L->W + x] = r.second;
+    }
+    L->flush(cnt);
+  });
+}
+void oracle_level_get_dst(Level* L, int d, float* disparity, float* cost, float* confidence) {
+  const size_t n = size_t(L->W) * L->H * 4;
+  if (disparity) {
+    memcpy(disparity, L->disparity[d].d.data(), n);
+  }
+  if (cost) {
+    memcpy(cost, L->cost[d].d.data(), n);
+  }
+  if (confidence) {
+    memcpy(confidence, L->confidence[d].d.data(), n);
+  }
+}
+void oracle_level_get_fov_mask(Level* L, int d, uint8_t* out) {
+  memcpy(out, L->fovMask[d].d.data(), size_t(L->W) * L->H);
+}
+void oracle_level_get_variance(Level* L, int s, float* out) {
+  memcpy(out, L->srcVariance[s].d.data(), size_t(L->W) * L->H * 4);
+}
+// which: 0 projWarp (float2), 1 projWarpInv (float2), 2 projColor (u16x3), 3 projColorBias (u16x3)
+void oracle_level_get_proj(Level* L, int d, int s, int which, void* out) {
+  const int i = L->idx(d, s);
+  const size_t px = size_t(L->W) * L->H;
+  switch (which) {
+    case 0:
+      memcpy(out, L->projWarp[i].d.data(), px * 8);
+      break;
+    case 1:
+      memcpy(out, L->projWarpInv[i].d.data(), px * 8);
+      break;
+    case 2:
+      memcpy(out, L->projColor[i].d.data(), px * 6);
+      break;
+    case 3:
+      memcpy(out, L->projColorBias[i].d.data(), px * 6);
+      break;
+  }
+}
+void oracle_level_get_counters(Level* L, uint64_t* nCost, uint64_t* nPair, int* insufficient, int* checkFailed) {
+  *nCost = L->nCost;
+  *nPair = L->nPair;
+  *insufficient = L->insufficientCoverage;
+  *checkFailed = L->coverageCheckFailed;
+}
+float oracle_level_var_noise_floor(Level* L) {
+  return L->varNoiseFloor;
+}
+
+// ---- upsample (UpsampleDisparityLib.cpp:149-182): rig must be normalised ----
+void oracle_upsample_disparity(
+    const OracleRig* rigDst,
+    int d,
+    const float* disp,
+    int w,
+    int h,
+    const float* bgDispUp,
+    const uint8_t* fgMask,
+    const uint8_t* fgMaskUp,
+    int wUp,
+    int hUp,
+    int useFg,
+    float* out) {
+  Img<float> in(w, h);
+  memcpy(in.d.data(), disp, size_t(w) * h * 4);
+  Img<float> bg;
+  Img<uint8_t> m, mUp;
+  if (useFg) {
+    bg = Img<float>(wUp, hUp);
+    memcpy(bg.d.data(), bgDispUp, size_t(wUp) * hUp * 4);
+    m = generateFovMask(rigDst->cams[d], w, h);
+    mUp = generateFovMask(rigDst->cams[d], wUp, hUp);
+    for (size_t i = 0; i < m.d.size(); ++i) {
+      m.d[i] &= fgMask[i];
+    }
+    for (size_t i = 0; i < mUp.d.size(); ++i) {
+      mUp.d[i] &= fgMaskUp[i];
+    }
+  }
+  const Img<float> up = upsampleDisparity(in, bg, m, mUp, wUp, hUp, useFg != 0);
+  memcpy(out, up.d.data(), size_t(wUp) * hUp * 4);
+}
+
+// ---- standalone filters ----
+void oracle_joint_bilateral_u16(
+    const float* image, const uint16_t* guide, const uint8_t* mask, int w, int h, int radius, float sigma,
+    float w0, float w1, float w2, int threads, float* out) {
+  Img<float> im(w, h);
+  memcpy(im.d.data(), image, size_t(w) * h * 4);
+  Img<Px3w> g(w, h);
+  memcpy(g.d.data(), guide, size_t(w) * h * 6);
+  Img<uint8_t> m(w, h);
+  memcpy(m.d.data(), mask, size_t(w) * h);
+  const Img<float> r = generalizedJointBilateralFilterU16(im, g, g, m, radius, sigma, w0, w1, w2, threads);
+  memcpy(out, r.d.data(), size_t(w) * h * 4);
+}
+void oracle_joint_bilateral_f32(
+    const float* image, const float* guide, const uint8_t* mask, int w, int h, int radius, float sigma,
+    float w0, float w1, float w2, int threads, float* out) {
+  Img<float> im(w, h);
+  memcpy(im.d.data(), image, size_t(w) * h * 4);
+  Img<Px3f> g(w, h);
+  memcpy(g.d.data(), guide, size_t(w) * h * 12);
+  Img<uint8_t> m(w, h);
+  memcpy(m.d.data(), mask, size_t(w) * h);
+  const Img<float> r = generalizedJointBilateralFilterF32(im, g, m, radius, sigma, w0, w1, w2, threads);
+  memcpy(out, r.d.data(), size_t(w) * h * 4);
+}
+void oracle_masked_median(
+    const float* image, const float* background, const uint8_t* mask, int w, int h, int radius, float* out) {
+  Img<float> im(w, h), bg;
+  memcpy(im.d.data(), image, size_t(w) * h * 4);
+  if (background) {
+    bg = Img<float>(w, h);
+    memcpy(bg.d.data(), background, size_t(w) * h * 4);
+  }
+  Img<uint8_t> m(w, h);
+  memcpy(m.d.data(), mask, size_t(w) * h);
+  const Img<float> r = maskedMedianBlur(im, bg, m, radius);
+  memcpy(out, r.d.data(), size_t(w) * h * 4);
+}
+// TemporalBilateralFilter.cpp:121-184 core: n frames of (guide, disparity, mask=fg&fov)
+void oracle_temporal_filter(
+    const uint16_t* const* guides, const float* const* images, const uint8_t* const* masks, int n, int w, int h,
+    int frameOffset, float sigma, int spatialRadius, float w0, float w1, float w2, int threads, float* out) {
+  std::vector<const Px3w*> g(n);
+  std::vector<const float*> im(n);
+  std::vector<const uint8_t*> m(n);
+  for (int i = 0; i < n; ++i) {
+    g[i] = reinterpret_cast<const Px3w*>(guides[i]);
+    im[i] = images[i];
+    m[i] = masks[i];
+  }
+  const Img<float> r =
+      temporalJointBilateralFilter(g, im, m, w, h, frameOffset, sigma, spatialRadius, w0, w1, w2, threads);
+  memcpy(out, r.d.data(), size_t(w) * h * 4);
+}
+int oracle_temporal_space_radius(int level) { // TemporalBilateralFilter.cpp:165-168
+  const float scale = std::pow(kLevelScale, level);
+  return std::max(std::ceil(1 * scale), float(1));
+}
+int oracle_bilateral_radius(int level) {
+  return bilateralRadius(level);
+}
+int oracle_upsample_radius(int w, int wUp) {
+  return getUpsampleRadius(w, wUp);
+}
+
+// ---- cv primitives exposed for unit tests ----
+void oracle_cv_remap_cubic_u16c3(const uint16_t* src, int sw, int sh, const float* map, int dw, int dh, uint16_t* out) {
+  Img<Px3w> s(sw, sh);
+  memcpy(s.d.data(), src, size_t(sw) * sh * 6);
+  Img<Px2f> m(dw, dh);
+  memcpy(m.d.data(), map, size_t(dw) * dh * 8);
+  Img<Px3w> d;
+  remapCubicU16C3(s, m, d);
+  memcpy(out, d.d.data(), size_t(dw) * dh * 6);
+}
+void oracle_cv_blur3_u16c3(const uint16_t* src, int w, int h, uint16_t* out) {
+  Img<Px3w> s(w, h), d;
+  memcpy(s.d.data(), src, size_t(w) * h * 6);
+  blur3x3U16C3(s, d);
+  memcpy(out, d.d.data(), size_t(w) * h * 6);
+}
+void oracle_cv_blur3_f32c3(const float* src, int w, int h, float* out) {
+  Img<Px3f> s(w, h), d;
+  memcpy(s.d.data(), src, size_t(w) * h * 12);
+  blur3x3F32C3(s, d);
+  memcpy(out, d.d.data(), size_t(w) * h * 12);
+}
+void oracle_cv_resize_lanczos4(const float* src, int sw, int sh, int dw, int dh, float* out) {
+  Img<float> s(sw, sh), d;
+  memcpy(s.d.data(), src, size_t(sw) * sh * 4);
+  resizeLanczos4F32(s, dw, dh, d);
+  memcpy(out, d.d.data(), size_t(dw) * dh * 4);
+}
+void oracle_cv_resize_nearest_f32(const float* src, int sw, int sh, int dw, int dh, float* out) {
+  Img<float> s(sw, sh), d;
+  memcpy(s.d.data(), src, size_t(sw) * sh * 4);
+  resizeNearest(s, dw, dh, d);
+  memcpy(out, d.d.data(), size_t(dw) * dh * 4);
+}
+void oracle_cv_variance(const uint16_t* src, int w, int h, float* out) {
+  Img<Px3w> s(w, h);
+  memcpy(s.d.data(), src, size_t(w) * h * 6);
+  const Img<float> v = computeImageVariance(s);
+  memcpy(out, v.d.data(), size_t(w) * h * 4);
+}
+// libstdc++ behaviours the random-proposal stage depends on (Derp.cpp:757-758,806-808)
+void oracle_minstd_uniform(int seed, int n, float a, float b, float* out) {
+  std::default_random_engine engine;
+  engine.seed(seed);
+  for (int i = 0; i < n; ++i) {
+    out[i] = std::uniform_real_distribution<float>(a, b)(engine);
+  }
+}
+// std::nth_element on pair<float,float> (Derp.cpp:210): permuted array back to the caller
+void oracle_nth_element_pairs(float* pairs, int n, int nth) {
+  std::pair<float, float>* p = reinterpret_cast<std::pair<float, float>*>(pairs);
+  std::nth_element(p, p + nth, p + n);
+}
+
+} // extern "C"

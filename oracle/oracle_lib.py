@@ -1,0 +1,428 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY. ctypes binding of oracle/libderp_oracle.so.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+The product (facebook360_dep_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+CAM_TYPES = {"FTHETA": 0, "RECTILINEAR": 1, "EQUISOLID": 2, "ORTHOGRAPHIC": 3}
+
+
+class CameraJson(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32),
+        ("has_principal", C.c_int32),
+        ("has_distortion", C.c_int32),
+        ("has_fov", C.c_int32),
+        ("origin", C.c_double * 3),
+        ("forward", C.c_double * 3),
+        ("up", C.c_double * 3),
+        ("right", C.c_double * 3),
+        ("resolution", C.c_double * 2),
+        ("focal", C.c_double * 2),
+        ("principal", C.c_double * 2),
+        ("distortion", C.c_double * 3),
+        ("fov", C.c_double),
+        ("id", C.c_char * 64),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("level", C.c_int32),
+        ("numLevels", C.c_int32),
+        ("width", C.c_int32),
+        ("height", C.c_int32),
+        ("widthFull", C.c_int32),
+        ("heightFull", C.c_int32),
+        ("minDepthM", C.c_float),
+        ("maxDepthM", C.c_float),
+        ("varNoiseFloorFull", C.c_float),
+        ("varHighThresh", C.c_float),
+        ("randomProposals", C.c_int32),
+        ("pingPongIterations", C.c_int32),
+        ("mismatchesStartLevel", C.c_int32),
+        ("doBilateral", C.c_int32),
+        ("doMedian", C.c_int32),
+        ("useFgMasks", C.c_int32),
+        ("partialCoverage", C.c_int32),
+        ("threads", C.c_int32),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libderp_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("derp_oracle.cpp", "oracle_camera.h", "oracle_cv.h")]
+    if force or not os.path.exists(so) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(so) for s in srcs
+    ):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        L = _LIB
+        L.oracle_rig_create.restype = C.c_void_p
+        L.oracle_level_create.restype = C.c_void_p
+        L.oracle_cam_get_fov.restype = C.c_double
+        L.oracle_cam_distort.restype = C.c_double
+        L.oracle_cam_undistort.restype = C.c_double
+        L.oracle_level_var_noise_floor.restype = C.c_float
+    return _LIB
+
+
+def camera_json(cam):
+    """cam: dict with the reference's rig-JSON keys (Camera.cpp:30-75)."""
+    j = CameraJson()
+    j.type = CAM_TYPES[cam["type"]]
+    for k in ("origin", "forward", "up", "right", "resolution", "focal"):
+        for i, v in enumerate(cam[k]):
+            getattr(j, k)[i] = float(v)
+    j.has_principal = int("principal" in cam)
+    if "principal" in cam:
+        j.principal[0], j.principal[1] = map(float, cam["principal"])
+    j.has_distortion = int("distortion" in cam)
+    if "distortion" in cam:
+        d = list(cam["distortion"]) + [0.0] * (3 - len(cam["distortion"]))
+        for i in range(3):
+            j.distortion[i] = float(d[i])
+    j.has_fov = int("fov" in cam)
+    if "fov" in cam:
+        j.fov = float(cam["fov"])
+    j.id = cam["id"].encode()
+    return j
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+class Rig:
+    def __init__(self, cams):
+        self.cams = list(cams)
+        arr = (CameraJson * len(cams))(*[camera_json(c) for c in cams])
+        self.h = C.c_void_p(lib().oracle_rig_create(arr, len(cams)))
+        self.n = len(cams)
+
+    def __del__(self):
+        try:
+            lib().oracle_rig_destroy(self.h)
+        except Exception:
+            pass
+
+    def ids(self):
+        return [c["id"] for c in self.cams]
+
+    def valid(self, i):
+        return bool(lib().oracle_cam_valid(self.h, i))
+
+    def normalize(self):
+        lib().oracle_rig_normalize(self.h)
+        return self
+
+    def rescale(self, i, w, h):
+        lib().oracle_cam_rescale(self.h, i, C.c_double(w), C.c_double(h))
+
+    def state(self, i):
+        out = np.zeros(23)
+        lib().oracle_cam_get(self.h, i, _p(out))
+        return dict(
+            position=out[0:3], R=out[3:12].reshape(3, 3), resolution=out[12:14], principal=out[14:16],
+            focal=out[16:18], distortion=out[18:21], distortion_max=out[21], cos_fov=out[22],
+        )
+
+    def set_fov(self, i, fov=None):
+        lib().oracle_cam_set_fov(self.h, i, C.c_double(0.0 if fov is None else fov), int(fov is None))
+
+    def get_fov(self, i):
+        return lib().oracle_cam_get_fov(self.h, i)
+
+    def set_distortion(self, i, d=None):
+        dd = np.zeros(3) if d is None else np.asarray(d, dtype=np.float64)
+        lib().oracle_cam_set_distortion(self.h, i, _p(dd), int(d is None))
+
+    def pixel(self, i, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        out = np.zeros((len(xyz), 2))
+        lib().oracle_cam_pixel(self.h, i, _p(xyz), len(xyz), _p(out))
+        return out
+
+    def rig(self, i, pix, depth):
+        pix = np.ascontiguousarray(pix, dtype=np.float64).reshape(-1, 2)
+        depth = np.ascontiguousarray(np.broadcast_to(np.asarray(depth, dtype=np.float64), (len(pix),)))
+        out = np.zeros((len(pix), 3))
+        lib().oracle_cam_rig(self.h, i, _p(pix), _p(depth), len(pix), _p(out))
+        return out
+
+    def sees(self, i, xyz):
+        xyz = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        s = np.zeros(len(xyz), dtype=np.uint8)
+        pix = np.zeros((len(xyz), 2))
+        lib().oracle_cam_sees(self.h, i, _p(xyz), len(xyz), _p(s), _p(pix))
+        return s.astype(bool), pix
+
+    def is_outside_image_circle(self, i, px, py):
+        return bool(lib().oracle_cam_is_outside_image_circle(self.h, i, C.c_double(px), C.c_double(py)))
+
+    def is_outside_sensor(self, i, px, py):
+        return bool(lib().oracle_cam_is_outside_sensor(self.h, i, C.c_double(px), C.c_double(py)))
+
+    def is_behind(self, i, p):
+        return bool(lib().oracle_cam_is_behind(self.h, i, C.c_double(p[0]), C.c_double(p[1]), C.c_double(p[2])))
+
+    def distort(self, i, v):
+        return lib().oracle_cam_distort(self.h, i, C.c_double(v))
+
+    def undistort(self, i, v):
+        return lib().oracle_cam_undistort(self.h, i, C.c_double(v))
+
+
+def make_params(level, num_levels, w, h, w_full, h_full, **kw):
+    """Defaults = DerpCLI.cpp:40-67."""
+    p = Params()
+    p.level, p.numLevels, p.width, p.height, p.widthFull, p.heightFull = level, num_levels, w, h, w_full, h_full
+    p.minDepthM = kw.get("min_depth_m", 0.5)
+    p.maxDepthM = kw.get("max_depth_m", 1e4)
+    p.varNoiseFloorFull = kw.get("var_noise_floor", 4e-5)
+    p.varHighThresh = kw.get("var_high_thresh", 1e-3)
+    p.randomProposals = kw.get("random_proposals", 2)
+    p.pingPongIterations = kw.get("ping_pong_iterations", 1)
+    p.mismatchesStartLevel = kw.get("mismatches_start_level", -1)
+    p.doBilateral = int(kw.get("do_bilateral_filter", True))
+    p.doMedian = int(kw.get("do_median_filter", True))
+    p.useFgMasks = int(kw.get("use_foreground_masks", False))
+    p.partialCoverage = int(kw.get("partial_coverage", False))
+    p.threads = kw.get("threads", -1)
+    return p
+
+
+class Level:
+    """One (frame, level) of the reference's PyramidLevel (PyramidLevel.h:24-131)."""
+
+    def __init__(self, rig_src, rig_dst, dst2src, params):
+        self.rig_src, self.rig_dst = rig_src, rig_dst
+        self.p = params
+        self.W, self.H = params.width, params.height
+        self.S, self.D = rig_src.n, rig_dst.n
+        d2s = np.asarray(dst2src, dtype=np.int32)
+        self.h = C.c_void_p(lib().oracle_level_create(rig_src.h, rig_dst.h, _p(d2s), C.byref(params)))
+
+    def __del__(self):
+        try:
+            lib().oracle_level_destroy(self.h)
+        except Exception:
+            pass
+
+    def set_src(self, s, bgr, fg=None):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint16)
+        assert bgr.shape == (self.H, self.W, 3)
+        fg = None if fg is None else np.ascontiguousarray(fg, dtype=np.uint8)
+        lib().oracle_level_set_src(self.h, s, _p(bgr), _p(fg))
+
+    def set_dst(self, d, disparity=None, bg=None):
+        disparity = None if disparity is None else np.ascontiguousarray(disparity, dtype=np.float32)
+        bg = None if bg is None else np.ascontiguousarray(bg, dtype=np.float32)
+        lib().oracle_level_set_dst(self.h, d, _p(disparity), _p(bg))
+
+    def precompute_projections(self):
+        lib().oracle_level_precompute_projections(self.h)
+
+    def reproject_colors(self):
+        lib().oracle_level_reproject_colors(self.h)
+
+    def brute_force(self):
+        lib().oracle_level_brute_force(self.h)
+
+    def random_proposals(self):
+        lib().oracle_level_random_proposals(self.h)
+
+    def ping_pong(self):
+        lib().oracle_level_ping_pong(self.h)
+
+    def bilateral(self):
+        lib().oracle_level_bilateral(self.h)
+
+    def median(self):
+        lib().oracle_level_median(self.h)
+
+    def mask_fov(self):
+        lib().oracle_level_mask_fov(self.h)
+
+    def process(self):
+        lib().oracle_level_process(self.h)
+
+    def cost_map(self, d, disp):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        cost = np.full((self.H, self.W), np.nan, dtype=np.float32)
+        conf = np.full((self.H, self.W), np.nan, dtype=np.float32)
+        lib().oracle_level_cost_map(self.h, d, _p(disp), _p(cost), _p(conf))
+        return cost, conf
+
+    def get_dst(self, d):
+        out = [np.zeros((self.H, self.W), dtype=np.float32) for _ in range(3)]
+        lib().oracle_level_get_dst(self.h, d, _p(out[0]), _p(out[1]), _p(out[2]))
+        return out  # disparity, cost, confidence
+
+    def fov_mask(self, d):
+        out = np.zeros((self.H, self.W), dtype=np.uint8)
+        lib().oracle_level_get_fov_mask(self.h, d, _p(out))
+        return out
+
+    def variance(self, s):
+        out = np.zeros((self.H, self.W), dtype=np.float32)
+        lib().oracle_level_get_variance(self.h, s, _p(out))
+        return out
+
+    def proj(self, d, s, which):
+        shp = {"warp": (2, np.float32, 0), "warp_inv": (2, np.float32, 1), "color": (3, np.uint16, 2),
+               "bias": (3, np.uint16, 3)}[which]
+        out = np.zeros((self.H, self.W, shp[0]), dtype=shp[1])
+        lib().oracle_level_get_proj(self.h, d, s, shp[2], _p(out))
+        return out
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        c, d = C.c_int(), C.c_int()
+        lib().oracle_level_get_counters(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(n_cost=a.value, n_pair=b.value, insufficient=c.value, check_failed=d.value)
+
+    def var_noise_floor(self):
+        return lib().oracle_level_var_noise_floor(self.h)
+
+
+def upsample_disparity(rig_dst_norm, d, disp, w_up, h_up, bg_up=None, fg=None, fg_up=None):
+    disp = np.ascontiguousarray(disp, dtype=np.float32)
+    h, w = disp.shape
+    use = fg is not None
+    out = np.zeros((h_up, w_up), dtype=np.float32)
+    if use:
+        bg_up = np.ascontiguousarray(bg_up, dtype=np.float32)
+        fg = np.ascontiguousarray(fg, dtype=np.uint8)
+        fg_up = np.ascontiguousarray(fg_up, dtype=np.uint8)
+    lib().oracle_upsample_disparity(rig_dst_norm.h, d, _p(disp), w, h, _p(bg_up) if use else None,
+                                    _p(fg) if use else None, _p(fg_up) if use else None, w_up, h_up, int(use), _p(out))
+    return out
+
+
+def joint_bilateral_u16(image, guide, mask, radius, sigma, w0, w1, w2, threads=-1):
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    guide = np.ascontiguousarray(guide, dtype=np.uint16)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = image.shape
+    out = np.zeros_like(image)
+    lib().oracle_joint_bilateral_u16(_p(image), _p(guide), _p(mask), w, h, radius, C.c_float(sigma), C.c_float(w0),
+                                     C.c_float(w1), C.c_float(w2), threads, _p(out))
+    return out
+
+
+def joint_bilateral_f32(image, guide, mask, radius, sigma, w0, w1, w2, threads=-1):
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    guide = np.ascontiguousarray(guide, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = image.shape
+    out = np.zeros_like(image)
+    lib().oracle_joint_bilateral_f32(_p(image), _p(guide), _p(mask), w, h, radius, C.c_float(sigma), C.c_float(w0),
+                                     C.c_float(w1), C.c_float(w2), threads, _p(out))
+    return out
+
+
+def masked_median(image, background, mask, radius=1):
+    image = np.ascontiguousarray(image, dtype=np.float32)
+    background = None if background is None else np.ascontiguousarray(background, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = image.shape
+    out = np.zeros_like(image)
+    lib().oracle_masked_median(_p(image), _p(background), _p(mask), w, h, radius, _p(out))
+    return out
+
+
+def temporal_filter(guides, images, masks, frame_offset, sigma, radius, w0, w1, w2, threads=-1):
+    n = len(guides)
+    guides = [np.ascontiguousarray(g, dtype=np.uint16) for g in guides]
+    images = [np.ascontiguousarray(g, dtype=np.float32) for g in images]
+    masks = [np.ascontiguousarray(g, dtype=np.uint8) for g in masks]
+    h, w = images[0].shape
+    gp = (C.c_void_p * n)(*[g.ctypes.data for g in guides])
+    ip = (C.c_void_p * n)(*[g.ctypes.data for g in images])
+    mp = (C.c_void_p * n)(*[g.ctypes.data for g in masks])
+    out = np.zeros((h, w), dtype=np.float32)
+    lib().oracle_temporal_filter(gp, ip, mp, n, w, h, frame_offset, C.c_float(sigma), radius, C.c_float(w0),
+                                 C.c_float(w1), C.c_float(w2), threads, _p(out))
+    return out
+
+
+def temporal_space_radius(level):
+    return lib().oracle_temporal_space_radius(level)
+
+
+def bilateral_radius(level):
+    return lib().oracle_bilateral_radius(level)
+
+
+def upsample_radius(w, w_up):
+    return lib().oracle_upsample_radius(w, w_up)
+
+
+def cv_remap_cubic(src, mp):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    mp = np.ascontiguousarray(mp, dtype=np.float32)
+    out = np.zeros(mp.shape[:2] + (3,), dtype=np.uint16)
+    lib().oracle_cv_remap_cubic_u16c3(_p(src), src.shape[1], src.shape[0], _p(mp), mp.shape[1], mp.shape[0], _p(out))
+    return out
+
+
+def cv_blur3_u16(src):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    out = np.zeros_like(src)
+    lib().oracle_cv_blur3_u16c3(_p(src), src.shape[1], src.shape[0], _p(out))
+    return out
+
+
+def cv_blur3_f32(src):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.zeros_like(src)
+    lib().oracle_cv_blur3_f32c3(_p(src), src.shape[1], src.shape[0], _p(out))
+    return out
+
+
+def cv_resize_lanczos4(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.zeros((dh, dw), dtype=np.float32)
+    lib().oracle_cv_resize_lanczos4(_p(src), src.shape[1], src.shape[0], dw, dh, _p(out))
+    return out
+
+
+def cv_resize_nearest(src, dw, dh):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    out = np.zeros((dh, dw), dtype=np.float32)
+    lib().oracle_cv_resize_nearest_f32(_p(src), src.shape[1], src.shape[0], dw, dh, _p(out))
+    return out
+
+
+def cv_variance(src):
+    src = np.ascontiguousarray(src, dtype=np.uint16)
+    out = np.zeros(src.shape[:2], dtype=np.float32)
+    lib().oracle_cv_variance(_p(src), src.shape[1], src.shape[0], _p(out))
+    return out
+
+
+def minstd_uniform(seed, n, a, b):
+    out = np.zeros(n, dtype=np.float32)
+    lib().oracle_minstd_uniform(seed, n, C.c_float(a), C.c_float(b), _p(out))
+    return out
+
+
+def nth_element_pairs(pairs, nth):
+    p = np.ascontiguousarray(pairs, dtype=np.float32).copy()
+    lib().oracle_nth_element_pairs(_p(p), len(p), nth)
+    return p
