@@ -1,0 +1,1520 @@
+// C-ABI implementation of include/derp_hip.h: context, HBM-resident pyramid, level driver.
+// Host side mirrors the reference's DerpCLI level loop (DerpCLI.cpp:220-323) and processLevel
+// (Derp.cpp:1005-1034). No CPU compute path: every stage is a kernel in derp_kernels.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/derp_hip.h"
+#include "derp_kernels.h"
+
+using namespace derp;
+
+namespace {
+
+enum Stage {
+  ST_FOV = 0,
+  ST_VARIANCE,
+  ST_OWN_BIAS,
+  ST_UPSAMPLE,
+  ST_PROJ_WARP,
+  ST_REPROJECT,
+  ST_PROJ_BIAS,
+  ST_BRUTE,
+  ST_RANDOM,
+  ST_PINGPONG,
+  ST_BILATERAL,
+  ST_MEDIAN,
+  ST_MASKFOV,
+  ST_COUNT
+};
+const char* kStageNames[ST_COUNT] = {"fov_mask",  "variance",    "own_bias",         "upsample",  "proj_warp",
+                                     "reproject", "proj_bias",   "brute_force",      "random_proposals",
+                                     "ping_pong", "bilateral",   "median",           "mask_fov"};
+constexpr int kMaxLevels = 24;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t n) {
+    if (n <= bytes) {
+      return 0;
+    }
+    if (p) {
+      (void)hipFree(p);
+      p = nullptr;
+      bytes = 0;
+    }
+    if (hipMalloc(&p, n) != hipSuccess) {
+      p = nullptr;
+      return 1;
+    }
+    bytes = n;
+    return 0;
+  }
+  void release() {
+    if (p) {
+      (void)hipFree(p);
+    }
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+struct TimedSpan {
+  int stage, level;
+  hipEvent_t a, b;
+};
+
+struct LanczosTab {
+  DevBuf ofs, coef;
+};
+
+}  // namespace
+
+struct derp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  derp_options opt;
+  int S = 0, D = 0;
+  std::vector<Cam> camsSrcH, camsDstH;
+  std::vector<int> dst2srcH;
+  DevBuf camsSrc, camsDst, dst2src;
+
+  int numLevels = 0, widthFull = 0, heightFull = 0;
+  std::vector<int> LW, LH;
+  // HBM-resident pyramid
+  std::vector<DevBuf> pyrColor, pyrFg, pyrBg, pyrDisp;
+  std::vector<char> haveBg, haveDisp;
+
+  // working level
+  int cur = -1;
+  int DB = 0;  // dst batch that fits the table budget
+  DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank;
+  DevBuf projWarp, projColor, projBias, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
+  int warpCachedLevel = -1;
+  bool tablesValid = false;
+  DevBuf counters;  // [ST_COUNT][kMaxLevels][4] u64
+  std::map<std::pair<int, int>, LanczosTab*> lanczos;
+  DevBuf spiral;
+  int spiralN = 0, spiralRadius = -1;
+
+  bool profiling = false;
+  std::vector<TimedSpan> spans;
+  double accMs[ST_COUNT][kMaxLevels];
+  int accLaunch[ST_COUNT][kMaxLevels];
+};
+
+namespace {
+
+int fail(derp_ctx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) {
+    c->err = buf;
+  }
+  return 1;
+}
+
+#define HIPCHK(c, expr)                                                                   \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) {                                                               \
+      return fail(c, "HIP error %s at %s:%d (%s)", hipGetErrorString(e_), __FILE__, __LINE__, #expr); \
+    }                                                                                     \
+  } while (0)
+#define ALLOC(c, buf, n)                                                         \
+  do {                                                                           \
+    if ((buf).ensure(n)) {                                                       \
+      return fail(c, "out of device memory allocating %zu bytes (%s)", (size_t)(n), #buf); \
+    }                                                                            \
+  } while (0)
+#define KCHECK(c) HIPCHK(c, hipGetLastError())
+#define TRY(expr)       \
+  do {                  \
+    int r_ = (expr);    \
+    if (r_) {           \
+      return r_;        \
+    }                   \
+  } while (0)
+
+struct Span {
+  derp_ctx* c;
+  int stage, level;
+  hipEvent_t a = nullptr, b = nullptr;
+  Span(derp_ctx* ctx, int st, int lv) : c(ctx), stage(st), level(lv) {
+    if (c->profiling) {
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~Span() {
+    if (c->profiling && a) {
+      (void)hipEventRecord(b, c->stream);
+      c->spans.push_back({stage, level, a, b});
+    }
+  }
+};
+
+void drain_spans(derp_ctx* c) {
+  for (auto& s : c->spans) {
+    (void)hipEventSynchronize(s.b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s.a, s.b);
+    if (s.level >= 0 && s.level < kMaxLevels) {
+      c->accMs[s.stage][s.level] += ms;
+      c->accLaunch[s.stage][s.level] += 1;
+    }
+    (void)hipEventDestroy(s.a);
+    (void)hipEventDestroy(s.b);
+  }
+  c->spans.clear();
+}
+
+size_t npx(const derp_ctx* c, int level) {
+  return (size_t)c->LW[level] * c->LH[level];
+}
+
+unsigned long long* counter_slot(derp_ctx* c, int stage, int level) {
+  return c->counters.as<unsigned long long>() + ((size_t)stage * kMaxLevels + level) * 4;
+}
+
+LevelView make_view(derp_ctx* c, int stage, int dst0, int nd) {
+  LevelView V;
+  const int L = c->cur;
+  V.W = c->LW[L];
+  V.H = c->LH[L];
+  V.S = c->S;
+  V.D = nd;
+  V.level = L;
+  V.numLevels = c->numLevels;
+  V.dst0 = dst0;
+  V.hasFg = c->opt.use_foreground_masks;
+  // PyramidLevel.h:232-236 — scale = float(width) / heightFullSize (reference quirk kept)
+  const float scale = float(V.W) / c->heightFull;
+  const float scaleVar = scale * scale;
+  V.varNoiseFloor = std::max(c->opt.var_noise_floor * scaleVar, kMinVar);
+  V.varHighThresh = c->opt.var_high_thresh;
+  V.minDepthM = c->opt.min_depth_m;
+  V.maxDepthM = c->opt.max_depth_m;
+  V.randomProposals = c->opt.random_proposals;
+  V.partialCoverage = c->opt.partial_coverage;
+  V.camsSrc = c->camsSrc.as<Cam>();
+  V.camsDst = c->camsDst.as<Cam>();
+  V.dst2src = c->dst2src.as<int>();
+  V.srcColor = c->pyrColor[L].as<ushort4>();
+  V.ownBias = c->ownBias.as<ushort4>();
+  V.srcVar = c->srcVar.as<float>();
+  V.srcFg = c->pyrFg[L].as<uint8_t>();
+  V.projWarp = c->projWarp.as<float2>();
+  V.projColor = c->projColor.as<ushort4>();
+  V.projBias = c->projBias.as<ushort4>();
+  V.disparity = c->disparity.as<float>();
+  V.cost = c->cost.as<float>();
+  V.confidence = c->confidence.as<float>();
+  V.bgDisp = c->pyrBg[L].as<float>();
+  V.fovMask = c->fovMask.as<uint8_t>();
+  V.counters = counter_slot(c, stage, L);
+  return V;
+}
+
+dim3 grid2d(int w, int h, int z, dim3 b) {
+  return dim3((w + b.x - 1) / b.x, (h + b.y - 1) / b.y, z);
+}
+const dim3 kBlk2d(32, 8, 1);
+
+int flat_grid(size_t n) {
+  return (int)std::min<size_t>((n + 255) / 256, 2048 * 4);
+}
+
+// ---- Lanczos4 tables: resize.cpp interpolateLanczos4 + offset computation (fp64 libm on host) ----
+void lanczos_coeffs(float x, float* coeffs) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0}, {-s45, -s45}, {0, 1}, {s45, -s45}, {-1, 0}, {s45, s45}, {0, -1}, {-s45, s45}};
+  if (x < 1.1920928955078125e-07f) {
+    for (int i = 0; i < 8; i++) {
+      coeffs[i] = 0;
+    }
+    coeffs[3] = 1;
+    return;
+  }
+  float sum = 0;
+  const double y0 = -(x + 3) * M_PI * 0.25, s0 = std::sin(y0), c0 = std::cos(y0);
+  for (int i = 0; i < 8; i++) {
+    const double y = -(x + 3 - i) * M_PI * 0.25;
+    coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) {
+    coeffs[i] *= sum;
+  }
+}
+
+int get_lanczos(derp_ctx* c, int ssize, int dsize, LanczosTab** out) {
+  auto key = std::make_pair(ssize, dsize);
+  auto it = c->lanczos.find(key);
+  if (it != c->lanczos.end()) {
+    *out = it->second;
+    return 0;
+  }
+  std::vector<int> ofs(dsize);
+  std::vector<float> coef((size_t)dsize * 8);
+  const double scale = (double)ssize / dsize;
+  for (int d = 0; d < dsize; ++d) {
+    float f = (float)((d + 0.5) * scale - 0.5);
+    int s = (int)f;
+    s -= (s > f);  // cvFloor
+    f -= s;
+    ofs[d] = s;
+    lanczos_coeffs(f, &coef[(size_t)d * 8]);
+  }
+  LanczosTab* t = new LanczosTab;
+  ALLOC(c, t->ofs, ofs.size() * sizeof(int));
+  ALLOC(c, t->coef, coef.size() * sizeof(float));
+  HIPCHK(c, hipMemcpyAsync(t->ofs.p, ofs.data(), ofs.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(t->coef.p, coef.data(), coef.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  c->lanczos[key] = t;
+  *out = t;
+  return 0;
+}
+
+// UpsampleDisparityLib.cpp:27-54 — clockwise outward spiral of diameter w
+std::vector<int2> make_spiral(int w) {
+  int x = 0, y = 0, dx = 0, dy = -1, t = w;
+  const int samples = t * t;
+  std::vector<int2> locs;
+  for (int i = 0; i < samples; ++i) {
+    const bool vx = (-w / 2 <= x) && (x <= w / 2), vy = (-w / 2 <= y) && (y <= w / 2);
+    if (vx && vy) {
+      locs.push_back(make_int2(x, y));
+    }
+    if (x == y || ((x < 0) && (x == -y)) || ((x > 0) && (x == 1 - y))) {
+      t = dx;
+      dx = -dy;
+      dy = t;
+    }
+    x += dx;
+    y += dy;
+  }
+  return locs;
+}
+
+int ensure_spiral(derp_ctx* c, int radius) {
+  if (c->spiralRadius == radius) {
+    return 0;
+  }
+  const std::vector<int2> s = make_spiral(radius * 2 + 1);
+  ALLOC(c, c->spiral, s.size() * sizeof(int2));
+  HIPCHK(c, hipMemcpy(c->spiral.p, s.data(), s.size() * sizeof(int2), hipMemcpyHostToDevice));
+  c->spiralN = (int)s.size();
+  c->spiralRadius = radius;
+  return 0;
+}
+
+// upsampleDisparityInPlace for `nd` planes living on the device (Lanczos path) or one plane (mask path)
+int upsample_lanczos_dev(derp_ctx* c, const float* in, int sw, int sh, float* out, int dw, int dh, int planes,
+                         size_t inStride, size_t outStride) {
+  if (sw == dw && sh == dh) {  // cv::resize to the same size is a copy (after NaN -> 1e-4)
+    return fail(c, "upsample to identical size not supported");
+  }
+  LanczosTab *tx, *ty;
+  TRY(get_lanczos(c, sw, dw, &tx));
+  TRY(get_lanczos(c, sh, dh, &ty));
+  const size_t tmpStride = (size_t)dw * sh;
+  ALLOC(c, c->lanczosTmp, tmpStride * planes * sizeof(float));
+  hipLaunchKernelGGL(k_lanczos_h, grid2d(dw, sh, planes, kBlk2d), kBlk2d, 0, c->stream, in, sw, sh, dw,
+                     tx->ofs.as<int>(), tx->coef.as<float>(), c->lanczosTmp.as<float>(), inStride, tmpStride);
+  KCHECK(c);
+  hipLaunchKernelGGL(k_lanczos_v, grid2d(dw, dh, planes, kBlk2d), kBlk2d, 0, c->stream, c->lanczosTmp.as<float>(), sh,
+                     dw, dh, ty->ofs.as<int>(), ty->coef.as<float>(), out, tmpStride, outStride);
+  KCHECK(c);
+  return 0;
+}
+
+int upsample_masked_dev(derp_ctx* c, const float* in, const uint8_t* mask, int sw, int sh, const uint8_t* maskUp,
+                        const float* bgUp, float* out, int dw, int dh) {
+  // getRadius (UpsampleDisparityLib.cpp:93-96): int(scale*scale + 1), float arithmetic
+  const float scale = float(dw) / float(sw);
+  const int radius = (int)(scale * scale + 1);
+  TRY(ensure_spiral(c, radius));
+  ALLOC(c, c->lanczosTmp, (size_t)dw * dh * sizeof(float));
+  hipLaunchKernelGGL(k_upsample_nearest_masked, grid2d(dw, dh, 1, kBlk2d), kBlk2d, 0, c->stream, in, mask, sw, sh,
+                     maskUp, dw, dh, c->lanczosTmp.as<float>());
+  KCHECK(c);
+  hipLaunchKernelGGL(k_spiral_fill, grid2d(dw, dh, 1, kBlk2d), kBlk2d, 0, c->stream, c->lanczosTmp.as<float>(), bgUp,
+                     maskUp, dw, dh, c->spiral.as<int2>(), c->spiralN, out);
+  KCHECK(c);
+  return 0;
+}
+
+size_t table_bytes_per_dst(const derp_ctx* c, int W, int H) {
+  const size_t wp = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW), cp = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC);
+  return (size_t)(c->S - 1) * (wp * sizeof(float2) + 2 * cp * sizeof(ushort4));
+}
+
+int compute_fov_and_masks(derp_ctx* c, int level) {
+  const int W = c->LW[level], H = c->LH[level];
+  const size_t n = (size_t)W * H;
+  {
+    Span sp(c, ST_FOV, level);
+    hipLaunchKernelGGL(k_fov_mask, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), W, H,
+                       c->fovMask.as<uint8_t>());
+    KCHECK(c);
+    hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), c->D), dim3(256), 0, c->stream, c->fovMask.as<uint8_t>(),
+                       c->pyrFg[level].as<uint8_t>(), c->dst2src.as<int>(), 0, n, c->maskAnd.as<uint8_t>());
+    KCHECK(c);
+  }
+  return 0;
+}
+
+int build_warp(derp_ctx* c, int dst0, int nd) {
+  const int L = c->cur;
+  Span sp(c, ST_PROJ_WARP, L);
+  LevelView V = make_view(c, ST_PROJ_WARP, dst0, nd);
+  hipLaunchKernelGGL(k_proj_warp, grid2d(V.W + 2 * kPadW, V.H + 2 * kPadW, c->S, kBlk2d), kBlk2d, 0, c->stream, V,
+                     c->projWarp.as<float2>());
+  KCHECK(c);
+  return 0;
+}
+
+int build_color_tables(derp_ctx* c, int dst0, int nd) {
+  const int L = c->cur;
+  LevelView V = make_view(c, ST_REPROJECT, dst0, nd);
+  {
+    Span sp(c, ST_REPROJECT, L);
+    hipLaunchKernelGGL(k_reproject, grid2d(V.W + 2 * kPadC, V.H + 2 * kPadC, nd, kBlk2d), kBlk2d, 0, c->stream, V,
+                       c->projColor.as<ushort4>());
+    KCHECK(c);
+  }
+  {
+    Span sp(c, ST_PROJ_BIAS, L);
+    const size_t plane = (size_t)(V.W + 2 * kPadC) * (V.H + 2 * kPadC);
+    const int planes = nd * (c->S - 1);
+    // grid.z is limited to 65535
+    for (int p0 = 0; p0 < planes; p0 += 32768) {
+      const int np = std::min(32768, planes - p0);
+      hipLaunchKernelGGL(k_blur3_u16, grid2d(V.W + 2 * kPadC, V.H + 2 * kPadC, np, kBlk2d), kBlk2d, 0, c->stream,
+                         c->projColor.as<ushort4>() + (size_t)p0 * plane, kPadC,
+                         c->projBias.as<ushort4>() + (size_t)p0 * plane, kPadC, V.W, V.H, plane, plane);
+      KCHECK(c);
+    }
+  }
+  return 0;
+}
+
+int tiles_of(int W, int H, int& tilesX) {
+  tilesX = (W + 15) / 16;
+  return tilesX * ((H + 15) / 16);
+}
+int round8(int n) {
+  return (n + 7) / 8 * 8;
+}
+
+int run_brute_force(derp_ctx* c, int dst0, int nd) {
+  const int L = c->cur;
+  if (L != c->numLevels - 1) {
+    return 0;
+  }
+  Span sp(c, ST_BRUTE, L);
+  LevelView V = make_view(c, ST_BRUTE, dst0, nd);
+  const size_t n = (size_t)V.W * V.H;
+  ALLOC(c, c->bruteCost, (size_t)nd * kNumDepths * n * sizeof(float));
+  ALLOC(c, c->bruteConf, (size_t)nd * kNumDepths * n * sizeof(float));
+  int tilesX;
+  const int tiles = tiles_of(V.W, V.H, tilesX);
+  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
+  hipLaunchKernelGGL(k_brute_costs, dim3(tiles, kNumDepths, nd), dim3(256), lds, c->stream, V,
+                     c->bruteCost.as<float>(), c->bruteConf.as<float>(), tilesX, tiles);
+  KCHECK(c);
+  hipLaunchKernelGGL(k_brute_select, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->bruteCost.as<float>(),
+                     c->bruteConf.as<float>());
+  KCHECK(c);
+  hipLaunchKernelGGL(k_brute_margin, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V);
+  KCHECK(c);
+  return 0;
+}
+
+int run_random_proposals(derp_ctx* c, int dst0, int nd) {
+  const int L = c->cur;
+  if (c->opt.random_proposals <= 0 || L == c->numLevels - 1) {
+    return 0;
+  }
+  Span sp(c, ST_RANDOM, L);
+  LevelView V = make_view(c, ST_RANDOM, dst0, nd);
+  if (V.H > 2 && V.W > 2) {
+    hipLaunchKernelGGL(k_row_rank, dim3(V.H - 2, nd), dim3(256), 0, c->stream, V, c->rank.as<int>());
+    KCHECK(c);
+  }
+  int tilesX;
+  const int tiles = tiles_of(V.W, V.H, tilesX);
+  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
+  hipLaunchKernelGGL(k_random_proposals, dim3(round8(tiles), nd), dim3(256), lds, c->stream, V, c->rank.as<int>(),
+                     tilesX, tiles);
+  KCHECK(c);
+  return 0;
+}
+
+int run_ping_pong(derp_ctx* c, int dst0, int nd) {
+  const int L = c->cur;
+  if (L == c->numLevels - 1) {
+    return 0;
+  }
+  Span sp(c, ST_PINGPONG, L);
+  LevelView V = make_view(c, ST_PINGPONG, dst0, nd);
+  const size_t n = (size_t)V.W * V.H;
+  HIPCHK(c, hipMemsetAsync(c->changed.as<uint8_t>() + (size_t)dst0 * n, 1, n * nd, c->stream));
+  int tilesX;
+  const int tiles = tiles_of(V.W, V.H, tilesX);
+  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
+  for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
+    hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(256), lds, c->stream, V, c->changed.as<uint8_t>(),
+                       c->dispRes.as<float>(), c->costRes.as<float>(), tilesX, tiles);
+    KCHECK(c);
+    hipLaunchKernelGGL(k_ping_pong_commit, dim3(flat_grid(n * nd)), dim3(256), 0, c->stream,
+                       c->disparity.as<float>() + (size_t)dst0 * n, c->cost.as<float>() + (size_t)dst0 * n,
+                       c->dispRes.as<float>() + (size_t)dst0 * n, c->costRes.as<float>() + (size_t)dst0 * n,
+                       c->changed.as<uint8_t>() + (size_t)dst0 * n, n * nd);
+    KCHECK(c);
+  }
+  return 0;
+}
+
+int bilateral_radius(int level) {  // Derp.cpp:876-878
+  const float scale = std::pow(0.9f, level);
+  return (int)std::max(std::ceil(5 * scale), float(1));
+}
+
+int run_bilateral(derp_ctx* c) {
+  const int L = c->cur;
+  Span sp(c, ST_BILATERAL, L);
+  const int W = c->LW[L], H = c->LH[L];
+  const size_t n = (size_t)W * H;
+  // weights passed (B, G, R) = (0.5, 1, 1) — Derp.cpp:893-896, Derp.h:44-48; sigma 0.005
+  hipLaunchKernelGGL(k_joint_bilateral_u16, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->disparity.as<float>(),
+                     c->pyrColor[L].as<ushort4>(), c->maskAnd.as<uint8_t>(), (const uint8_t*)nullptr, W, H,
+                     bilateral_radius(L), 0.005f, 0.5f, 1.0f, 1.0f, c->tmpF.as<float>(), n, n, c->dst2src.as<int>());
+  KCHECK(c);
+  HIPCHK(c, hipMemcpyAsync(c->disparity.p, c->tmpF.p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int run_median(derp_ctx* c, bool fuseMaskFov) {
+  const int L = c->cur;
+  Span sp(c, ST_MEDIAN, L);
+  const int W = c->LW[L], H = c->LH[L];
+  const size_t n = (size_t)W * H;
+  hipLaunchKernelGGL(k_masked_median, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->disparity.as<float>(),
+                     c->opt.use_foreground_masks ? c->pyrBg[L].as<float>() : (const float*)nullptr,
+                     c->maskAnd.as<uint8_t>(), W, H, 1, c->tmpF.as<float>(), n,
+                     fuseMaskFov ? c->fovMask.as<uint8_t>() : (const uint8_t*)nullptr);
+  KCHECK(c);
+  HIPCHK(c, hipMemcpyAsync(c->disparity.p, c->tmpF.p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
+int run_mask_fov(derp_ctx* c) {
+  const int L = c->cur;
+  Span sp(c, ST_MASKFOV, L);
+  const size_t n = npx(c, L) * c->D;
+  hipLaunchKernelGGL(k_mask_fov, dim3(flat_grid(n)), dim3(256), 0, c->stream, c->disparity.as<float>(),
+                     c->fovMask.as<uint8_t>(), n);
+  KCHECK(c);
+  return 0;
+}
+
+int check_level(derp_ctx* c, int level) {
+  if (!c || c->numLevels == 0) {
+    return fail(c, "derp_set_pyramid has not been called");
+  }
+  if (level < 0 || level >= c->numLevels) {
+    return fail(c, "level %d out of range [0, %d)", level, c->numLevels);
+  }
+  return 0;
+}
+
+// Level set-up: what DerpCLI does before processLevel (DerpCLI.cpp:221-303)
+int level_begin(derp_ctx* c, int level, bool buildAllTables) {
+  TRY(check_level(c, level));
+  if (c->S - 1 > kMaxSrc) {
+    return fail(c, "too many source cameras (%d > %d)", c->S, kMaxSrc + 1);
+  }
+  c->cur = level;
+  const int W = c->LW[level], H = c->LH[level];
+  const size_t n = (size_t)W * H;
+  if (W < 3 || H < 3) {
+    return fail(c, "level %d is too small (%dx%d)", level, W, H);
+  }
+  TRY(compute_fov_and_masks(c, level));
+  {
+    Span sp(c, ST_VARIANCE, level);
+    hipLaunchKernelGGL(k_variance, grid2d(W, H, c->S, kBlk2d), kBlk2d, 0, c->stream, c->pyrColor[level].as<ushort4>(),
+                       W, H, c->srcVar.as<float>());
+    KCHECK(c);
+  }
+  {
+    Span sp(c, ST_OWN_BIAS, level);
+    hipLaunchKernelGGL(k_blur3_u16, grid2d(W, H, c->S, kBlk2d), kBlk2d, 0, c->stream,
+                       c->pyrColor[level].as<ushort4>(), 0, c->ownBias.as<ushort4>(), 0, W, H, n, n);
+    KCHECK(c);
+  }
+  // fresh PyramidLevel: disparity / cost / confidence start at 0 (PyramidLevel.h:209-221)
+  HIPCHK(c, hipMemsetAsync(c->cost.p, 0, n * c->D * sizeof(float), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->confidence.p, 0, n * c->D * sizeof(float), c->stream));
+  if (level < c->numLevels - 1 && !c->haveDisp[level + 1] && !buildAllTables) {
+    return fail(c, "Missing disparity of level %d needed to start level %d", level + 1, level);
+  }
+  if (level < c->numLevels - 1 && c->haveDisp[level + 1]) {
+    Span sp(c, ST_UPSAMPLE, level);
+    const int sw = c->LW[level + 1], sh = c->LH[level + 1];
+    if (!c->opt.use_foreground_masks) {
+      TRY(upsample_lanczos_dev(c, c->pyrDisp[level + 1].as<float>(), sw, sh, c->disparity.as<float>(), W, H, c->D,
+                               (size_t)sw * sh, n));
+    } else {
+      // masks = fov & fg at both sizes (UpsampleDisparityLib.cpp:163-179); coarse fov&fg recomputed into tmpF bytes
+      ALLOC(c, c->staging, (size_t)sw * sh * c->D);
+      hipLaunchKernelGGL(k_fov_mask, grid2d(sw, sh, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), sw, sh,
+                         c->staging.as<uint8_t>());
+      KCHECK(c);
+      hipLaunchKernelGGL(k_and_masks, dim3(flat_grid((size_t)sw * sh), c->D), dim3(256), 0, c->stream,
+                         c->staging.as<uint8_t>(), c->pyrFg[level + 1].as<uint8_t>(), c->dst2src.as<int>(), 0,
+                         (size_t)sw * sh, c->staging.as<uint8_t>());
+      KCHECK(c);
+      for (int d = 0; d < c->D; ++d) {
+        TRY(upsample_masked_dev(c, c->pyrDisp[level + 1].as<float>() + (size_t)d * sw * sh,
+                                c->staging.as<uint8_t>() + (size_t)d * sw * sh, sw, sh,
+                                c->maskAnd.as<uint8_t>() + (size_t)d * n, c->pyrBg[level].as<float>() + (size_t)d * n,
+                                c->disparity.as<float>() + (size_t)d * n, W, H));
+      }
+    }
+  } else {
+    HIPCHK(c, hipMemsetAsync(c->disparity.p, 0, n * c->D * sizeof(float), c->stream));
+  }
+  // table budget -> dst batch
+  size_t freeB = 0, totalB = 0;
+  HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+  const size_t per = table_bytes_per_dst(c, W, H);
+  size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes;
+  if (const char* e = getenv("DERP_TABLE_BUDGET_GB")) {
+    budget = std::min<size_t>(budget, (size_t)(atof(e) * (1ull << 30)));
+  } else {
+    budget = (size_t)(budget * 0.85);
+  }
+  int DB = (int)std::min<size_t>((size_t)c->D, budget / std::max<size_t>(per, 1));
+  if (DB < 1) {
+    return fail(c, "projection tables for one destination (%zu bytes) exceed the table budget (%zu bytes)", per, budget);
+  }
+  c->DB = DB;
+  const size_t wp = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW), cp = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC);
+  ALLOC(c, c->projWarp, (size_t)DB * (c->S - 1) * wp * sizeof(float2));
+  ALLOC(c, c->projColor, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
+  ALLOC(c, c->projBias, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
+  c->tablesValid = false;
+  if (buildAllTables) {
+    if (DB < c->D) {
+      return fail(c, "stage-level API needs all destinations' tables resident (batch %d < %d)", DB, c->D);
+    }
+    if (c->opt.rebuild_warp_tables || c->warpCachedLevel != level) {
+      TRY(build_warp(c, 0, c->D));
+      c->warpCachedLevel = level;
+    }
+  }
+  return 0;
+}
+
+int level_end(derp_ctx* c) {
+  const int L = c->cur;
+  HIPCHK(c, hipMemcpyAsync(c->pyrDisp[L].p, c->disparity.p, npx(c, L) * c->D * sizeof(float),
+                           hipMemcpyDeviceToDevice, c->stream));
+  c->haveDisp[L] = 1;
+  return 0;
+}
+
+int process_level(derp_ctx* c, int level) {
+  TRY(level_begin(c, level, false));
+  const int L = level;
+  for (int d0 = 0; d0 < c->D; d0 += c->DB) {
+    const int nd = std::min(c->DB, c->D - d0);
+    const bool single = (c->DB == c->D);
+    if (!single || c->opt.rebuild_warp_tables || c->warpCachedLevel != L) {
+      TRY(build_warp(c, d0, nd));
+      c->warpCachedLevel = single ? L : -1;
+    }
+    TRY(build_color_tables(c, d0, nd));
+    TRY(run_brute_force(c, d0, nd));
+    TRY(run_random_proposals(c, d0, nd));
+    TRY(run_ping_pong(c, d0, nd));
+  }
+  if (c->opt.do_bilateral_filter) {
+    TRY(run_bilateral(c));
+  }
+  if (c->opt.do_median_filter) {
+    TRY(run_median(c, true));
+  } else {
+    TRY(run_mask_fov(c));
+  }
+  TRY(level_end(c));
+  return 0;
+}
+
+int need_current(derp_ctx* c, bool tables) {
+  if (!c || c->cur < 0) {
+    return fail(c, "derp_level_begin has not been called");
+  }
+  if (tables && !c->tablesValid) {
+    return fail(c, "derp_stage_reproject_colors must run before this stage");
+  }
+  return 0;
+}
+
+template <typename T>
+int upload_tmp(derp_ctx* c, DevBuf& buf, const T* host, size_t count) {
+  ALLOC(c, buf, count * sizeof(T));
+  HIPCHK(c, hipMemcpyAsync(buf.p, host, count * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  return 0;
+}
+
+}  // namespace
+
+// =========================================================================================
+extern "C" {
+
+void derp_options_default(derp_options* o) {
+  o->min_depth_m = 0.5f;
+  o->max_depth_m = 1e4f;
+  o->var_noise_floor = 4e-5f;
+  o->var_high_thresh = 1e-3f;
+  o->random_proposals = 2;
+  o->ping_pong_iterations = 1;
+  o->mismatches_start_level = -1;
+  o->do_bilateral_filter = 1;
+  o->do_median_filter = 1;
+  o->use_foreground_masks = 0;
+  o->partial_coverage = 0;
+  o->rebuild_warp_tables = 1;
+}
+
+static thread_local std::string g_create_error;
+
+int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_src, const derp_camera_desc* dst,
+                int n_dst) {
+  if (!out) {
+    return 1;
+  }
+  *out = nullptr;
+  derp_ctx* c = new derp_ctx;
+  derp_options_default(&c->opt);
+  memset(c->accMs, 0, sizeof c->accMs);
+  memset(c->accLaunch, 0, sizeof c->accLaunch);
+  auto bail = [&](const std::string& m) {
+    g_create_error = m;
+    delete c;
+    return 1;
+  };
+  if (n_src <= 0 || n_dst <= 0) {
+    return bail("no source / destination cameras!");
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    return bail("no HIP device present: the depth path has no CPU fallback");
+  }
+  if (device < 0 || device >= count) {
+    return bail("HIP device index out of range");
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    return bail("hipGetDeviceProperties failed");
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("DERP_ALLOW_ANY_ARCH")) {
+    return bail(std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    return bail("hipSetDevice failed");
+  }
+  c->device = device;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    return bail("hipStreamCreate failed");
+  }
+  c->S = n_src;
+  c->D = n_dst;
+  c->camsSrcH.resize(n_src);
+  c->camsDstH.resize(n_dst);
+  for (int i = 0; i < n_src; ++i) {
+    if (const char* m = host_prepare_camera(src[i], c->camsSrcH[i])) {
+      return bail(std::string("camera ") + src[i].id + ": " + m);
+    }
+  }
+  c->dst2srcH.assign(n_dst, 0);
+  for (int i = 0; i < n_dst; ++i) {
+    if (const char* m = host_prepare_camera(dst[i], c->camsDstH[i])) {
+      return bail(std::string("camera ") + dst[i].id + ": " + m);
+    }
+    bool found = false;
+    for (int s = 0; s < n_src; ++s) {  // mapSrcToDstIndexes, DerpUtil.cpp:75-89
+      if (strncmp(dst[i].id, src[s].id, sizeof dst[i].id) == 0) {
+        c->dst2srcH[i] = s;
+        found = true;
+        break;
+      }
+    }
+    if (!found) {
+      return bail(std::string("destination camera ") + dst[i].id + " is not a source camera");
+    }
+  }
+  if (c->camsSrc.ensure(sizeof(Cam) * n_src) || c->camsDst.ensure(sizeof(Cam) * n_dst) ||
+      c->dst2src.ensure(sizeof(int) * n_dst) || c->counters.ensure(sizeof(unsigned long long) * ST_COUNT * kMaxLevels * 4)) {
+    return bail("out of device memory");
+  }
+  (void)hipMemcpy(c->camsSrc.p, c->camsSrcH.data(), sizeof(Cam) * n_src, hipMemcpyHostToDevice);
+  (void)hipMemcpy(c->camsDst.p, c->camsDstH.data(), sizeof(Cam) * n_dst, hipMemcpyHostToDevice);
+  (void)hipMemcpy(c->dst2src.p, c->dst2srcH.data(), sizeof(int) * n_dst, hipMemcpyHostToDevice);
+  (void)hipMemset(c->counters.p, 0, c->counters.bytes);
+  *out = c;
+  return 0;
+}
+
+void derp_destroy(derp_ctx* c) {
+  if (!c) {
+    return;
+  }
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  drain_spans(c);
+  for (auto* v : {&c->pyrColor, &c->pyrFg, &c->pyrBg, &c->pyrDisp}) {
+    for (auto& b : *v) {
+      b.release();
+    }
+  }
+  for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
+                    &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank,
+                    &c->projWarp, &c->projColor, &c->projBias, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
+                    &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
+    b->release();
+  }
+  for (auto& kv : c->lanczos) {
+    kv.second->ofs.release();
+    kv.second->coef.release();
+    delete kv.second;
+  }
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* derp_last_error(const derp_ctx* c) {
+  return c ? c->err.c_str() : g_create_error.c_str();
+}
+
+int derp_set_options(derp_ctx* c, const derp_options* o) {
+  if (!c || !o) {
+    return 1;
+  }
+  if (o->mismatches_start_level != -1) {
+    return fail(c, "mismatches_start_level=%d: mismatch handling is not implemented (only -1)", o->mismatches_start_level);
+  }
+  if (o->random_proposals < 0) {
+    return fail(c, "Check failed: random_proposals >= 0");
+  }
+  c->opt = *o;
+  return 0;
+}
+
+int derp_set_pyramid(derp_ctx* c, int num_levels, const int* widths, const int* heights, int width_full,
+                     int height_full) {
+  if (!c) {
+    return 1;
+  }
+  if (num_levels <= 0 || num_levels > kMaxLevels) {
+    return fail(c, "num_levels %d out of range (1..%d)", num_levels, kMaxLevels);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  c->numLevels = num_levels;
+  c->widthFull = width_full;
+  c->heightFull = height_full;
+  c->LW.assign(widths, widths + num_levels);
+  c->LH.assign(heights, heights + num_levels);
+  c->pyrColor.resize(num_levels);
+  c->pyrFg.resize(num_levels);
+  c->pyrBg.resize(num_levels);
+  c->pyrDisp.resize(num_levels);
+  c->haveBg.assign(num_levels, 0);
+  c->haveDisp.assign(num_levels, 0);
+  size_t nmax = 0;
+  for (int l = 0; l < num_levels; ++l) {
+    const size_t n = npx(c, l);
+    nmax = std::max(nmax, n);
+    ALLOC(c, c->pyrColor[l], n * c->S * sizeof(ushort4));
+    ALLOC(c, c->pyrFg[l], n * c->S);
+    ALLOC(c, c->pyrBg[l], n * c->D * sizeof(float));
+    ALLOC(c, c->pyrDisp[l], n * c->D * sizeof(float));
+    HIPCHK(c, hipMemsetAsync(c->pyrFg[l].p, 1, n * c->S, c->stream));  // generateAllPassMasks
+    HIPCHK(c, hipMemsetAsync(c->pyrBg[l].p, 0, n * c->D * sizeof(float), c->stream));
+  }
+  ALLOC(c, c->srcVar, nmax * c->S * sizeof(float));
+  ALLOC(c, c->ownBias, nmax * c->S * sizeof(ushort4));
+  ALLOC(c, c->fovMask, nmax * c->D);
+  ALLOC(c, c->maskAnd, nmax * c->D);
+  for (DevBuf* b : {&c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->tmpF, &c->rank}) {
+    ALLOC(c, *b, nmax * c->D * sizeof(float));
+  }
+  ALLOC(c, c->changed, nmax * c->D);
+  c->cur = -1;
+  c->warpCachedLevel = -1;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int derp_upload_color(derp_ctx* c, int level, int s, const uint16_t* bgr) {
+  TRY(check_level(c, level));
+  if (s < 0 || s >= c->S || !bgr) {
+    return fail(c, "bad source index / null image");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = npx(c, level);
+  TRY(upload_tmp(c, c->staging, bgr, n * 3));
+  hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, c->staging.as<uint16_t>(),
+                     c->pyrColor[level].as<ushort4>() + (size_t)s * n, n);
+  KCHECK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // staging buffer is reused by the next upload
+  if (c->warpCachedLevel == level) {
+    // colour does not affect the warp tables; nothing to invalidate
+  }
+  return 0;
+}
+
+int derp_upload_foreground_mask(derp_ctx* c, int level, int s, const uint8_t* mask) {
+  TRY(check_level(c, level));
+  if (s < 0 || s >= c->S || !mask) {
+    return fail(c, "bad source index / null mask");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipMemcpy(c->pyrFg[level].as<uint8_t>() + (size_t)s * n, mask, n, hipMemcpyHostToDevice));
+  return 0;
+}
+
+int derp_upload_background_disparity(derp_ctx* c, int level, int d, const float* disp) {
+  TRY(check_level(c, level));
+  if (d < 0 || d >= c->D || !disp) {
+    return fail(c, "bad destination index / null image");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipMemcpy(c->pyrBg[level].as<float>() + (size_t)d * n, disp, n * sizeof(float), hipMemcpyHostToDevice));
+  c->haveBg[level] = 1;
+  return 0;
+}
+
+int derp_upload_disparity(derp_ctx* c, int level, int d, const float* disp) {
+  TRY(check_level(c, level));
+  if (d < 0 || d >= c->D || !disp) {
+    return fail(c, "bad destination index / null image");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipMemcpy(c->pyrDisp[level].as<float>() + (size_t)d * n, disp, n * sizeof(float), hipMemcpyHostToDevice));
+  c->haveDisp[level] = 1;
+  return 0;
+}
+
+int derp_process_level(derp_ctx* c, int level) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  return process_level(c, level);
+}
+
+int derp_process_pyramid(derp_ctx* c, int level_start, int level_end_) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (level_start < level_end_) {
+    return fail(c, "Check failed: level_start >= level_end (%d vs %d)", level_start, level_end_);
+  }
+  for (int level = level_start; level >= level_end_; --level) {
+    TRY(process_level(c, level));
+  }
+  return 0;
+}
+
+int derp_synchronize(derp_ctx* c) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // coverage CHECK of computeBruteForceDisparity (Derp.cpp:334-349)
+  if (c->numLevels > 0 && !c->opt.partial_coverage && !c->opt.use_foreground_masks) {
+    unsigned long long v[4];
+    HIPCHK(c, hipMemcpy(v, counter_slot(c, ST_BRUTE, c->numLevels - 1), sizeof v, hipMemcpyDeviceToHost));
+    if (v[2] != 0) {
+      return fail(c, "Check failed: partialCoverage || useForegroundMasks  Insufficient coverage at %llu pixels", v[2]);
+    }
+  }
+  return 0;
+}
+
+int derp_download_disparity(derp_ctx* c, int level, int d, float* disparity) {
+  TRY(check_level(c, level));
+  if (d < 0 || d >= c->D || !disparity) {
+    return fail(c, "bad destination index / null output");
+  }
+  if (!c->haveDisp[level]) {
+    return fail(c, "level %d has not been processed", level);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipMemcpy(disparity, c->pyrDisp[level].as<float>() + (size_t)d * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int derp_download_cost(derp_ctx* c, int d, float* cost, float* confidence) {
+  TRY(need_current(c, false));
+  if (d < 0 || d >= c->D) {
+    return fail(c, "bad destination index");
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = npx(c, c->cur);
+  if (cost) {
+    HIPCHK(c, hipMemcpy(cost, c->cost.as<float>() + (size_t)d * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  if (confidence) {
+    HIPCHK(c, hipMemcpy(confidence, c->confidence.as<float>() + (size_t)d * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  return 0;
+}
+
+// ---- stage-level API ----
+int derp_level_begin(derp_ctx* c, int level) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  return level_begin(c, level, true);
+}
+int derp_stage_reproject_colors(derp_ctx* c) {
+  TRY(need_current(c, false));
+  TRY(build_color_tables(c, 0, c->D));
+  c->tablesValid = true;
+  return 0;
+}
+int derp_stage_brute_force(derp_ctx* c) {
+  TRY(need_current(c, true));
+  return run_brute_force(c, 0, c->D);
+}
+int derp_stage_random_proposals(derp_ctx* c) {
+  TRY(need_current(c, true));
+  return run_random_proposals(c, 0, c->D);
+}
+int derp_stage_ping_pong(derp_ctx* c) {
+  TRY(need_current(c, true));
+  return run_ping_pong(c, 0, c->D);
+}
+int derp_stage_bilateral_filter(derp_ctx* c) {
+  TRY(need_current(c, false));
+  return run_bilateral(c);
+}
+int derp_stage_median_filter(derp_ctx* c) {
+  TRY(need_current(c, false));
+  return run_median(c, false);
+}
+int derp_stage_mask_fov(derp_ctx* c) {
+  TRY(need_current(c, false));
+  return run_mask_fov(c);
+}
+int derp_level_end(derp_ctx* c) {
+  TRY(need_current(c, false));
+  return level_end(c);
+}
+int derp_set_level_disparity(derp_ctx* c, int d, const float* disp) {
+  TRY(need_current(c, false));
+  if (d < 0 || d >= c->D || !disp) {
+    return fail(c, "bad destination index / null image");
+  }
+  const size_t n = npx(c, c->cur);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(c->disparity.as<float>() + (size_t)d * n, disp, n * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+int derp_get_level_disparity(derp_ctx* c, int d, float* disp) {
+  TRY(need_current(c, false));
+  if (d < 0 || d >= c->D || !disp) {
+    return fail(c, "bad destination index / null output");
+  }
+  const size_t n = npx(c, c->cur);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(disp, c->disparity.as<float>() + (size_t)d * n, n * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int derp_cost_map(derp_ctx* c, int d, const float* disp, float* cost, float* confidence) {
+  TRY(need_current(c, true));
+  if (d < 0 || d >= c->D || !disp || !cost || !confidence) {
+    return fail(c, "bad arguments");
+  }
+  const int L = c->cur;
+  const size_t n = npx(c, L);
+  TRY(upload_tmp(c, c->staging, disp, n));
+  ALLOC(c, c->stagingB, 2 * n * sizeof(float));
+  HIPCHK(c, hipMemsetAsync(c->stagingB.p, 0xff, 2 * n * sizeof(float), c->stream));  // NaN fill
+  LevelView V = make_view(c, ST_PINGPONG, 0, c->D);
+  int tilesX;
+  const int tiles = tiles_of(V.W, V.H, tilesX);
+  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
+  hipLaunchKernelGGL(k_cost_map, dim3(tiles), dim3(256), lds, c->stream, V, d, c->staging.as<float>(),
+                     c->stagingB.as<float>(), c->stagingB.as<float>() + n, tilesX);
+  KCHECK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(cost, c->stagingB.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(confidence, c->stagingB.as<float>() + n, n * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int derp_debug_download(derp_ctx* c, int d, int s, int which, void* out) {
+  TRY(need_current(c, false));
+  const int L = c->cur;
+  const int W = c->LW[L], H = c->LH[L];
+  const size_t n = (size_t)W * H;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (which == 4) {
+    HIPCHK(c, hipMemcpy(out, c->srcVar.as<float>() + (size_t)s * n, n * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (which == 5) {
+    HIPCHK(c, hipMemcpy(out, c->fovMask.as<uint8_t>() + (size_t)d * n, n, hipMemcpyDeviceToHost));
+    return 0;
+  }
+  if (d < 0 || d >= c->D || s < 0 || s >= c->S || s == c->dst2srcH[d]) {
+    return fail(c, "bad (dst, src) pair");
+  }
+  const size_t tab = (size_t)d * (c->S - 1) + (s < c->dst2srcH[d] ? s : s - 1);
+  if (which == 0) {
+    const int PW = W + 2 * kPadW, PH = H + 2 * kPadW;
+    std::vector<float2> tmp((size_t)PW * PH);
+    HIPCHK(c, hipMemcpy(tmp.data(), c->projWarp.as<float2>() + tab * tmp.size(), tmp.size() * sizeof(float2),
+                        hipMemcpyDeviceToHost));
+    float2* o = reinterpret_cast<float2*>(out);
+    for (int y = 0; y < H; ++y) {
+      memcpy(o + (size_t)y * W, &tmp[(size_t)(y + kPadW) * PW + kPadW], (size_t)W * sizeof(float2));
+    }
+    return 0;
+  }
+  if (which == 2 || which == 3) {
+    const int PW = W + 2 * kPadC, PH = H + 2 * kPadC;
+    std::vector<ushort4> tmp((size_t)PW * PH);
+    const ushort4* base = (which == 2 ? c->projColor.as<ushort4>() : c->projBias.as<ushort4>()) + tab * tmp.size();
+    HIPCHK(c, hipMemcpy(tmp.data(), base, tmp.size() * sizeof(ushort4), hipMemcpyDeviceToHost));
+    uint16_t* o = reinterpret_cast<uint16_t*>(out);
+    for (int y = 0; y < H; ++y) {
+      for (int x = 0; x < W; ++x) {
+        const ushort4 q = tmp[(size_t)(y + kPadC) * PW + x + kPadC];
+        o[((size_t)y * W + x) * 3 + 0] = q.x;
+        o[((size_t)y * W + x) * 3 + 1] = q.y;
+        o[((size_t)y * W + x) * 3 + 2] = q.z;
+      }
+    }
+    return 0;
+  }
+  return fail(c, "unknown table id %d", which);
+}
+
+// ---- sibling binaries' kernels, host-pointer convenience forms ----
+int derp_upsample_disparity(derp_ctx* c, int d, const float* disp, int w, int h, const float* bg_disp_up,
+                            const uint8_t* fg_mask, const uint8_t* fg_mask_up, int w_up, int h_up, int use_fg,
+                            float* out) {
+  if (!c || !disp || !out || d < 0 || d >= c->D) {
+    return fail(c, "bad arguments");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h, nu = (size_t)w_up * h_up;
+  DevBuf in, res, m, mu, bg, fov, fovu;
+  int rc = 0;
+  auto cleanup = [&]() {
+    for (DevBuf* b : {&in, &res, &m, &mu, &bg, &fov, &fovu}) {
+      b->release();
+    }
+  };
+  do {
+    if (in.ensure(n * 4) || res.ensure(nu * 4)) {
+      rc = fail(c, "out of device memory");
+      break;
+    }
+    (void)hipMemcpy(in.p, disp, n * 4, hipMemcpyHostToDevice);
+    if (!use_fg) {
+      rc = upsample_lanczos_dev(c, in.as<float>(), w, h, res.as<float>(), w_up, h_up, 1, n, nu);
+    } else {
+      if (!bg_disp_up || !fg_mask || !fg_mask_up) {
+        rc = fail(c, "foreground-mask upsample needs bg_disp_up, fg_mask and fg_mask_up");
+        break;
+      }
+      if (m.ensure(n) || mu.ensure(nu) || bg.ensure(nu * 4) || fov.ensure(n) || fovu.ensure(nu)) {
+        rc = fail(c, "out of device memory");
+        break;
+      }
+      (void)hipMemcpy(m.p, fg_mask, n, hipMemcpyHostToDevice);
+      (void)hipMemcpy(mu.p, fg_mask_up, nu, hipMemcpyHostToDevice);
+      (void)hipMemcpy(bg.p, bg_disp_up, nu * 4, hipMemcpyHostToDevice);
+      const int zero = 0;
+      DevBuf idx;
+      if (idx.ensure(sizeof(int))) {
+        rc = fail(c, "out of device memory");
+        break;
+      }
+      (void)hipMemcpy(idx.p, &zero, sizeof(int), hipMemcpyHostToDevice);
+      // fov masks of camera d at both sizes, AND-ed with the fg masks (UpsampleDisparityLib.cpp:163-179)
+      hipLaunchKernelGGL(k_fov_mask, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>() + d, w, h,
+                         fov.as<uint8_t>());
+      hipLaunchKernelGGL(k_fov_mask, grid2d(w_up, h_up, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>() + d,
+                         w_up, h_up, fovu.as<uint8_t>());
+      hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), 1), dim3(256), 0, c->stream, fov.as<uint8_t>(),
+                         m.as<uint8_t>(), idx.as<int>(), 0, n, fov.as<uint8_t>());
+      hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(nu), 1), dim3(256), 0, c->stream, fovu.as<uint8_t>(),
+                         mu.as<uint8_t>(), idx.as<int>(), 0, nu, fovu.as<uint8_t>());
+      rc = upsample_masked_dev(c, in.as<float>(), fov.as<uint8_t>(), w, h, fovu.as<uint8_t>(), bg.as<float>(),
+                               res.as<float>(), w_up, h_up);
+      (void)hipStreamSynchronize(c->stream);
+      idx.release();
+    }
+    if (rc) {
+      break;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(out, res.p, nu * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_upsample_disparity");
+    }
+  } while (0);
+  cleanup();
+  return rc;
+}
+
+int derp_joint_bilateral_u16(derp_ctx* c, const float* image, const uint16_t* guide, const uint8_t* mask, int w, int h,
+                             int radius, float sigma, float w0, float w1, float w2, float* out) {
+  if (!c || !image || !guide || !mask || !out) {
+    return fail(c, "bad arguments");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  DevBuf im, g3, g4, m, res;
+  int rc = 0;
+  if (im.ensure(n * 4) || g3.ensure(n * 6) || g4.ensure(n * 8) || m.ensure(n) || res.ensure(n * 4)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(im.p, image, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(g3.p, guide, n * 6, hipMemcpyHostToDevice);
+    (void)hipMemcpy(m.p, mask, n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, g3.as<uint16_t>(), g4.as<ushort4>(), n);
+    hipLaunchKernelGGL(k_joint_bilateral_u16, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, im.as<float>(),
+                       g4.as<ushort4>(), m.as<uint8_t>(), (const uint8_t*)nullptr, w, h, radius, sigma, w0, w1, w2,
+                       res.as<float>(), n, n, (const int*)nullptr);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, res.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_joint_bilateral_u16: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* b : {&im, &g3, &g4, &m, &res}) {
+    b->release();
+  }
+  return rc;
+}
+
+int derp_joint_bilateral_f32(derp_ctx* c, const float* image, const float* guide, const uint8_t* mask, int w, int h,
+                             int radius, float sigma, float w0, float w1, float w2, float* out) {
+  if (!c || !image || !guide || !mask || !out) {
+    return fail(c, "bad arguments");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  DevBuf im, g, m, res;
+  int rc = 0;
+  if (im.ensure(n * 4) || g.ensure(n * 12) || m.ensure(n) || res.ensure(n * 4)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(im.p, image, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(g.p, guide, n * 12, hipMemcpyHostToDevice);
+    (void)hipMemcpy(m.p, mask, n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_joint_bilateral_f32, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, im.as<float>(),
+                       g.as<float>(), m.as<uint8_t>(), w, h, radius, sigma, w0, w1, w2, res.as<float>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, res.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_joint_bilateral_f32: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* b : {&im, &g, &m, &res}) {
+    b->release();
+  }
+  return rc;
+}
+
+int derp_masked_median(derp_ctx* c, const float* image, const float* background, const uint8_t* mask, int w, int h,
+                       int radius, float* out) {
+  if (!c || !image || !mask || !out || radius < 1 || radius > 2) {
+    return fail(c, "bad arguments (radius must be 1 or 2)");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  DevBuf im, bg, m, res;
+  int rc = 0;
+  if (im.ensure(n * 4) || (background && bg.ensure(n * 4)) || m.ensure(n) || res.ensure(n * 4)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(im.p, image, n * 4, hipMemcpyHostToDevice);
+    if (background) {
+      (void)hipMemcpy(bg.p, background, n * 4, hipMemcpyHostToDevice);
+    }
+    (void)hipMemcpy(m.p, mask, n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_masked_median, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, im.as<float>(),
+                       background ? bg.as<float>() : (const float*)nullptr, m.as<uint8_t>(), w, h, radius,
+                       res.as<float>(), n, (const uint8_t*)nullptr);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, res.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_masked_median: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* b : {&im, &bg, &m, &res}) {
+    b->release();
+  }
+  return rc;
+}
+
+int derp_temporal_filter_dev(derp_ctx* c, const void* const* guides, const float* const* disps,
+                             const uint8_t* const* masks, int n_frames, int w, int h, int frame_offset, float sigma,
+                             int space_radius, float w0, float w1, float w2, float* out_dev) {
+  if (!c || n_frames < 1 || n_frames > 8 || frame_offset < 0 || frame_offset >= n_frames) {
+    return fail(c, "temporal window must hold 1..8 frames and contain the centre frame");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  TemporalFrames F;
+  F.n = n_frames;
+  for (int t = 0; t < n_frames; ++t) {
+    F.guides[t] = reinterpret_cast<const ushort4*>(guides[t]);
+    F.images[t] = disps[t];
+    F.masks[t] = masks[t];
+  }
+  hipLaunchKernelGGL(k_temporal, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, F, w, h, frame_offset, sigma,
+                     space_radius, w0, w1, w2, out_dev);
+  KCHECK(c);
+  return 0;
+}
+
+int derp_temporal_filter(derp_ctx* c, const uint16_t* const* guides, const float* const* disps,
+                         const uint8_t* const* masks, int n_frames, int w, int h, int frame_offset, float sigma,
+                         int space_radius, float w0, float w1, float w2, float* out) {
+  if (!c || n_frames < 1 || n_frames > 8) {
+    return fail(c, "temporal window must hold 1..8 frames");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  std::vector<DevBuf> g4(n_frames), im(n_frames), m(n_frames);
+  DevBuf g3, res;
+  int rc = 0;
+  const void* gp[8];
+  const float* ip[8];
+  const uint8_t* mp[8];
+  do {
+    if (g3.ensure(n * 6) || res.ensure(n * 4)) {
+      rc = fail(c, "out of device memory");
+      break;
+    }
+    for (int t = 0; t < n_frames && !rc; ++t) {
+      if (g4[t].ensure(n * 8) || im[t].ensure(n * 4) || m[t].ensure(n)) {
+        rc = fail(c, "out of device memory");
+        break;
+      }
+      (void)hipMemcpy(g3.p, guides[t], n * 6, hipMemcpyHostToDevice);
+      hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, g3.as<uint16_t>(),
+                         g4[t].as<ushort4>(), n);
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipMemcpy(im[t].p, disps[t], n * 4, hipMemcpyHostToDevice);
+      (void)hipMemcpy(m[t].p, masks[t], n, hipMemcpyHostToDevice);
+      gp[t] = g4[t].p;
+      ip[t] = im[t].as<float>();
+      mp[t] = m[t].as<uint8_t>();
+    }
+    if (rc) {
+      break;
+    }
+    rc = derp_temporal_filter_dev(c, gp, ip, mp, n_frames, w, h, frame_offset, sigma, space_radius, w0, w1, w2,
+                                  res.as<float>());
+    if (rc) {
+      break;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, res.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_temporal_filter: %s", hipGetErrorString(hipGetLastError()));
+    }
+  } while (0);
+  for (auto* v : {&g4, &im, &m}) {
+    for (auto& b : *v) {
+      b.release();
+    }
+  }
+  g3.release();
+  res.release();
+  return rc;
+}
+
+int derp_dev_disparity(derp_ctx* c, int level, int d, float** ptr, size_t* bytes) {
+  TRY(check_level(c, level));
+  const size_t n = npx(c, level);
+  *ptr = c->pyrDisp[level].as<float>() + (size_t)d * n;
+  *bytes = n * sizeof(float);
+  return 0;
+}
+int derp_dev_color(derp_ctx* c, int level, int s, void** ptr, size_t* bytes) {
+  TRY(check_level(c, level));
+  const size_t n = npx(c, level);
+  *ptr = c->pyrColor[level].as<ushort4>() + (size_t)s * n;
+  *bytes = n * sizeof(ushort4);
+  return 0;
+}
+int derp_dev_mask(derp_ctx* c, int level, int d, uint8_t** ptr, size_t* bytes) {
+  TRY(check_level(c, level));
+  HIPCHK(c, hipSetDevice(c->device));
+  // fov & fg of `level` (TemporalBilateralFilter.cpp:150-160); recomputed into the working mask buffers
+  TRY(compute_fov_and_masks(c, level));
+  const size_t n = npx(c, level);
+  *ptr = c->maskAnd.as<uint8_t>() + (size_t)d * n;
+  *bytes = n;
+  return 0;
+}
+
+int derp_get_counters(derp_ctx* c, uint64_t* n_cost, uint64_t* n_pair, uint64_t* insufficient) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<unsigned long long> h((size_t)ST_COUNT * kMaxLevels * 4);
+  HIPCHK(c, hipMemcpy(h.data(), c->counters.p, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  uint64_t a = 0, b = 0, i = 0;
+  for (size_t k = 0; k < h.size(); k += 4) {
+    a += h[k];
+    b += h[k + 1];
+    i += h[k + 2];
+  }
+  if (n_cost) {
+    *n_cost = a;
+  }
+  if (n_pair) {
+    *n_pair = b;
+  }
+  if (insufficient) {
+    *insufficient = i;
+  }
+  return 0;
+}
+int derp_reset_counters(derp_ctx* c) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipMemsetAsync(c->counters.p, 0, c->counters.bytes, c->stream));
+  return 0;
+}
+int derp_profile_enable(derp_ctx* c, int on) {
+  if (!c) {
+    return 1;
+  }
+  c->profiling = on != 0;
+  return 0;
+}
+int derp_profile_reset(derp_ctx* c) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_spans(c);
+  memset(c->accMs, 0, sizeof c->accMs);
+  memset(c->accLaunch, 0, sizeof c->accLaunch);
+  return derp_reset_counters(c);
+}
+int derp_profile_query(derp_ctx* c, const char* stage, int level, double* ms, int* launches, uint64_t* n_cost,
+                       uint64_t* n_pair) {
+  if (!c || !stage) {
+    return 1;
+  }
+  int st = -1;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (strcmp(stage, kStageNames[i]) == 0) {
+      st = i;
+    }
+  }
+  if (st < 0) {
+    return fail(c, "unknown stage '%s'", stage);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  drain_spans(c);
+  std::vector<unsigned long long> h((size_t)kMaxLevels * 4);
+  HIPCHK(c, hipMemcpy(h.data(), counter_slot(c, st, 0), h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  double m = 0;
+  int l = 0;
+  uint64_t a = 0, b = 0;
+  for (int lv = 0; lv < kMaxLevels; ++lv) {
+    if (level >= 0 && lv != level) {
+      continue;
+    }
+    m += c->accMs[st][lv];
+    l += c->accLaunch[st][lv];
+    a += h[(size_t)lv * 4];
+    b += h[(size_t)lv * 4 + 1];
+  }
+  if (ms) {
+    *ms = m;
+  }
+  if (launches) {
+    *launches = l;
+  }
+  if (n_cost) {
+    *n_cost = a;
+  }
+  if (n_pair) {
+    *n_pair = b;
+  }
+  return 0;
+}
+int derp_device_name(derp_ctx* c, char* buf, int n) {
+  if (!c || !buf || n <= 0) {
+    return 1;
+  }
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  snprintf(buf, n, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return 0;
+}
+
+// ---- host-only self checks ----
+namespace {
+struct HostPairs {
+  SsdPair* p;
+  SsdPair get(int i) const {
+    return p[i];
+  }
+  void set(int i, const SsdPair& v) {
+    p[i] = v;
+  }
+};
+}  // namespace
+int derp_host_nth_element_pairs(float* pairs, int n, int nth) {
+  HostPairs acc{reinterpret_cast<SsdPair*>(pairs)};
+  GccSelect<HostPairs> sel(acc);
+  sel.nth_element(nth, n);
+  return 0;
+}
+float derp_host_minstd_uniform(int seed, uint64_t draw_index, float a, float b) {
+  uint32_t state = minstd_jump(minstd_seed(seed), draw_index);
+  return minstd_uniform(state, a, b);
+}
+
+}  // extern "C"

@@ -1,0 +1,1199 @@
+// HIP kernels of the depth_estimation hot path for gfx950 (MI355X / CDNA4).
+//
+// Arithmetic follows the reference operation for operation (see each kernel's citation);
+// the translation unit is compiled with -ffp-contract=off (the reference's x86-64 build has
+// no FMA) and with correctly rounded fp32 divide/sqrt. MFMA is not used: the path is
+// gather / compare, not a dense contraction.
+//
+// HBM layout (per level):
+//   srcColor   [S][H][W]            ushort4 (B,G,R,0)          8 B texels, one aligned load
+//   ownBias    [S][H][W]            ushort4  3x3 box of srcColor (dstProjColorBias(dst))
+//   projWarp   [DB][S-1][H+2][W+2]  float2, 1-texel replicated ring  (clamp-to-edge taps
+//                                    of getPixelBilinear become plain loads)
+//   projColor  [DB][S-1][H+4][W+4]  ushort4, 2-texel replicated ring
+//   projBias   [DB][S-1][H+4][W+4]  ushort4, 2-texel replicated ring
+//   disparity / cost / confidence / variance  float [.][H][W]; masks uint8
+// A wave covers an 8x8 pixel tile (a 256-thread block a 16x16 tile) so that the 64 lanes'
+// gathers into one source table fall into a few neighbouring cache lines; blocks are
+// remapped so that each XCD (own L2) walks a contiguous band of tiles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "derp_camera.h"
+#include "gcc_algos.h"
+
+namespace derp {
+
+static constexpr int kPadW = 1;   // ring of projWarp
+static constexpr int kPadC = 2;   // ring of projColor / projBias
+static constexpr int kMaxSrc = 32;
+static constexpr int kNumDepths = 150;                 // Derp.h:33
+static constexpr float kMinVar = 1.0f / 12.0f / 65025.0f;  // DerpUtil.h:32
+
+typedef float f4a8 __attribute__((ext_vector_type(4), aligned(8)));
+typedef unsigned int u4a8 __attribute__((ext_vector_type(4), aligned(8)));
+
+struct LevelView {
+  int W, H, S, D;             // D = dst cameras in this batch
+  int level, numLevels;
+  int dst0;                   // first dst of the batch (global dst index = dst0 + dl)
+  int hasFg;
+  float varNoiseFloor, varHighThresh;
+  float minDepthM, maxDepthM;
+  int randomProposals;
+  int partialCoverage;
+  const Cam* camsSrc;         // [S] normalised
+  const Cam* camsDst;         // [Dtotal] normalised
+  const int* dst2src;         // [Dtotal]
+  const ushort4* srcColor;    // [S][H*W]
+  const ushort4* ownBias;     // [S][H*W]
+  const float* srcVar;        // [S][H*W]
+  const uint8_t* srcFg;       // [S][H*W]
+  const float2* projWarp;     // [D][S-1] padded
+  const ushort4* projColor;
+  const ushort4* projBias;
+  // per dst (global index)
+  float* disparity;           // [Dtotal][H*W]
+  float* cost;
+  float* confidence;
+  const float* bgDisp;        // [Dtotal][H*W] or null
+  const uint8_t* fovMask;     // [Dtotal][H*W]
+  unsigned long long* counters;  // [0] nCost [1] nPair [2] insufficient coverage [3] check failed
+};
+
+__device__ __forceinline__ size_t warp_plane(const LevelView& V) {
+  return (size_t)(V.W + 2 * kPadW) * (V.H + 2 * kPadW);
+}
+__device__ __forceinline__ size_t color_plane(const LevelView& V) {
+  return (size_t)(V.W + 2 * kPadC) * (V.H + 2 * kPadC);
+}
+__device__ __forceinline__ int slot(int s, int own) {
+  return s < own ? s : s - 1;
+}
+
+// XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give block b
+// the tile (b % 8) * ceil(n/8) + b / 8 — each XCD's L2 then serves one contiguous band.
+__device__ __forceinline__ int xcd_swizzle(int b, int n) {
+  const int per = (n + 7) >> 3;
+  const int t = (b & 7) * per + (b >> 3);
+  return t;
+}
+
+// pixel of a 16x16 tile handled by this thread: waves own 8x8 sub-tiles
+__device__ __forceinline__ void tile_pixel(int tile, int tilesX, int& x, int& y) {
+  const int tx = tile % tilesX, ty = tile / tilesX;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  x = tx * 16 + (wave & 1) * 8 + (lane & 7);
+  y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+}
+
+// ----------------------------------------------------------------------------------------
+// bilinear helpers — CvUtil.h:78-120. Weights: x - round(x) + 0.5; taps (xi-1, yi-1)..(xi, yi)
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float bilerp_f(float p00, float p01, float p10, float p11, float w00, float w01,
+                                          float w10, float w11) {
+  return w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+}
+// scalar bilerp<T = ushort>: float expression truncated to ushort
+__device__ __forceinline__ float bilerp_u16(float p00, float p01, float p10, float p11, float w00, float w01,
+                                            float w10, float w11) {
+  const float v = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
+  return (float)(((unsigned int)v) & 0xffffu);
+}
+
+struct PixCtx {
+  D3 rayO, rayD;        // dst ray (Camera::rig(pixel) of the dst pixel centre)
+  float patch[9][3];    // dst colour 3x3, index (dx+1)*3 + (dy+1) — computeSSD's loop order
+  float dstBias[3];
+  float confidence;     // max(variance, kMinVar)
+};
+
+// selection scratch in LDS: pairs[i][thread]
+struct LdsPairs {
+  SsdPair* base;
+  int stride;
+  __device__ __forceinline__ SsdPair get(int i) const {
+    return base[i * stride];
+  }
+  __device__ __forceinline__ void set(int i, const SsdPair& v) {
+    base[i * stride] = v;
+  }
+};
+
+// computeSSD (DerpUtil.cpp:126-162) for one source whose projected tables are `col` / `bias`.
+__device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
+                                               const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc) {
+  const int pitch = V.W + 2 * kPadC;
+  // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
+  float bias[3];
+  {
+    const float xf = roundf(xDstSrc), yf = roundf(yDstSrc);
+    const int xi = (int)xf, yi = (int)yf;
+    const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
+    const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
+    const ushort4* r0 = bia + (size_t)(yi - 1 + kPadC) * pitch + (xi - 1 + kPadC);
+    const u4a8 a = *reinterpret_cast<const u4a8*>(r0);
+    const u4a8 b = *reinterpret_cast<const u4a8*>(r0 + pitch);
+    const float p00[3] = {(float)(a.x & 0xffff), (float)(a.x >> 16), (float)(a.y & 0xffff)};
+    const float p01[3] = {(float)(a.z & 0xffff), (float)(a.z >> 16), (float)(a.w & 0xffff)};
+    const float p10[3] = {(float)(b.x & 0xffff), (float)(b.x >> 16), (float)(b.y & 0xffff)};
+    const float p11[3] = {(float)(b.z & 0xffff), (float)(b.z >> 16), (float)(b.w & 0xffff)};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float sb = bilerp_u16(p00[c], p01[c], p10[c], p11[c], w00, w01, w10, w11);
+      bias[c] = px.dstBias[c] - sb;
+    }
+  }
+  // --- per-offset tap positions and weights
+  int xi[3], yi[3];
+  float xw[3], yw[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float xs = xDstSrc + (float)(k - 1), ys = yDstSrc + (float)(k - 1);
+    const float xf = roundf(xs), yf = roundf(ys);
+    xi[k] = (int)xf;
+    yi[k] = (int)yf;
+    xw[k] = xs - xf + 0.5f;
+    yw[k] = ys - yf + 0.5f;
+  }
+  float first = 0.f, second = 0.f;
+  const bool regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
+  if (regular) {
+    // 4x4 texel block rows yi[1]-2 .. yi[1]+1, cols xi[1]-2 .. xi[1]+1
+    float t[4][4][3];
+    const ushort4* r = col + (size_t)(yi[1] - 2 + kPadC) * pitch + (xi[1] - 2 + kPadC);
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      const u4a8 a = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
+      const u4a8 b = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
+      t[row][0][0] = (float)(a.x & 0xffff);
+      t[row][0][1] = (float)(a.x >> 16);
+      t[row][0][2] = (float)(a.y & 0xffff);
+      t[row][1][0] = (float)(a.z & 0xffff);
+      t[row][1][1] = (float)(a.z >> 16);
+      t[row][1][2] = (float)(a.w & 0xffff);
+      t[row][2][0] = (float)(b.x & 0xffff);
+      t[row][2][1] = (float)(b.x >> 16);
+      t[row][2][2] = (float)(b.y & 0xffff);
+      t[row][3][0] = (float)(b.z & 0xffff);
+      t[row][3][1] = (float)(b.z >> 16);
+      t[row][3][2] = (float)(b.w & 0xffff);
+    }
+#pragma unroll
+    for (int ix = 0; ix < 3; ++ix) {
+#pragma unroll
+      for (int iy = 0; iy < 3; ++iy) {
+        const float w00 = (1 - xw[ix]) * (1 - yw[iy]), w01 = xw[ix] * (1 - yw[iy]);
+        const float w10 = (1 - xw[ix]) * yw[iy], w11 = xw[ix] * yw[iy];
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float cs = bilerp_u16(t[iy][ix][c], t[iy][ix + 1][c], t[iy + 1][ix][c], t[iy + 1][ix + 1][c], w00,
+                                      w01, w10, w11);
+          const float db = px.patch[ix * 3 + iy][c] - cs;
+          const float dn = db - bias[c];
+          d0 += db * db;
+          d1 += dn * dn;
+        }
+        first += d0;
+        second += d1;
+      }
+    }
+  } else {
+    // float rounding of x + dx crossed a .5 boundary: taps no longer form a 4x4 block
+    for (int ix = 0; ix < 3; ++ix) {
+      for (int iy = 0; iy < 3; ++iy) {
+        const float w00 = (1 - xw[ix]) * (1 - yw[iy]), w01 = xw[ix] * (1 - yw[iy]);
+        const float w10 = (1 - xw[ix]) * yw[iy], w11 = xw[ix] * yw[iy];
+        const int x0 = min(max(xi[ix] - 1, -kPadC), V.W + kPadC - 1), x1 = min(max(xi[ix], -kPadC), V.W + kPadC - 1);
+        const int y0 = min(max(yi[iy] - 1, -kPadC), V.H + kPadC - 1), y1 = min(max(yi[iy], -kPadC), V.H + kPadC - 1);
+        const ushort4 q00 = col[(size_t)(y0 + kPadC) * pitch + x0 + kPadC];
+        const ushort4 q01 = col[(size_t)(y0 + kPadC) * pitch + x1 + kPadC];
+        const ushort4 q10 = col[(size_t)(y1 + kPadC) * pitch + x0 + kPadC];
+        const ushort4 q11 = col[(size_t)(y1 + kPadC) * pitch + x1 + kPadC];
+        const float p00[3] = {(float)q00.x, (float)q00.y, (float)q00.z};
+        const float p01[3] = {(float)q01.x, (float)q01.y, (float)q01.z};
+        const float p10[3] = {(float)q10.x, (float)q10.y, (float)q10.z};
+        const float p11[3] = {(float)q11.x, (float)q11.y, (float)q11.z};
+        float d0 = 0.f, d1 = 0.f;
+        for (int c = 0; c < 3; ++c) {
+          const float cs = bilerp_u16(p00[c], p01[c], p10[c], p11[c], w00, w01, w10, w11);
+          const float db = px.patch[ix * 3 + iy][c] - cs;
+          const float dn = db - bias[c];
+          d0 += db * db;
+          d1 += dn * dn;
+        }
+        first += d0;
+        second += d1;
+      }
+    }
+  }
+  const float scale = 1.0f / (65535.0f * 65535.0f);
+  return {first * scale, second * scale};
+}
+
+// computeCost — Derp.cpp:104-226. `dl` = dst index inside the batch, `own` = dst2src.
+// Returns (cost, confidence); (FLT_MAX, 0) when fewer than kMinOverlappingCams-1 sources see it.
+__device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int own, const PixCtx& px, float disparity,
+                                               LdsPairs& pairs, unsigned& nPair) {
+  // dstToWorldPoint (DerpUtil.cpp:38-52): camDst.rig(p, 1.0f / disparity) — reciprocal in float
+  const double depth = (double)(1.0f / disparity);
+  const D3 pWorld = {px.rayO.x + px.rayD.x * depth, px.rayO.y + px.rayD.y * depth, px.rayO.z + px.rayD.z * depth};
+  const size_t wPlane = warp_plane(V), cPlane = color_plane(V);
+  const int wPitch = V.W + 2 * kPadW;
+  int ssdCount = 0;
+  for (int s = 0; s < V.S; ++s) {
+    if (s == own) {
+      continue;
+    }
+    const Cam& cs = V.camsSrc[s];
+    D2 pn;
+    // worldToSrcPoint (DerpUtil.cpp:56-73): Camera::sees on the normalised camera, then * (W, H)
+    if (!sees(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1], 1.0, 1.0, pn)) {
+      continue;
+    }
+    const float sx = (float)(pn.x * (double)V.W), sy = (float)(pn.y * (double)V.H);
+    const size_t tab = (size_t)dl * (V.S - 1) + slot(s, own);
+    // pDstSrc = getPixelBilinear(dstProjWarp, pSrc)
+    float xDstSrc, yDstSrc;
+    {
+      const float xf = roundf(sx), yf = roundf(sy);
+      const int xi = (int)xf, yi = (int)yf;
+      const float xw = sx - xf + 0.5f, yw = sy - yf + 0.5f;
+      const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
+      const float2* r0 = V.projWarp + tab * wPlane + (size_t)(yi - 1 + kPadW) * wPitch + (xi - 1 + kPadW);
+      const f4a8 a = *reinterpret_cast<const f4a8*>(r0);
+      const f4a8 b = *reinterpret_cast<const f4a8*>(r0 + wPitch);
+      const float wx = bilerp_f(a.x, a.z, b.x, b.z, w00, w01, w10, w11);
+      const float wy = bilerp_f(a.y, a.w, b.y, b.w, w00, w01, w10, w11);
+      xDstSrc = (float)((double)wx + 0.5);
+      yDstSrc = (float)((double)wy + 0.5);
+    }
+    if (isnan(xDstSrc) || isnan(yDstSrc)) {
+      continue;
+    }
+    ++nPair;
+    const SsdPair ssd =
+        compute_ssd(V, px, V.projColor + tab * cPlane, V.projBias + tab * cPlane, xDstSrc, yDstSrc);
+    pairs.set(ssdCount, ssd);
+    ++ssdCount;
+  }
+  int keep = 1;  // kMinOverlappingCams - 1
+  if (ssdCount < keep) {
+    return make_float2(3.402823466e+38f, 0.0f);
+  }
+  keep = max(keep, ssdCount - 2);
+  GccSelect<LdsPairs> sel(pairs);
+  sel.nth_element(keep, ssdCount);
+  float cost = 0;
+  for (int i = 0; i < keep; ++i) {
+    cost += pairs.get(i).second;
+  }
+  cost /= (float)keep;
+  const float trustCoef = 1.0f / (float)keep;
+  const float costFinal = cost * trustCoef / px.confidence;
+  return make_float2(costFinal, px.confidence);
+}
+
+// gather the per-pixel constants of computeCost: dst ray, 3x3 dst patch, dst bias, variance
+__device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, int x, int y, PixCtx& px) {
+  const Cam& cd = V.camsDst[d];
+  px.rayO = {cd.pos[0], cd.pos[1], cd.pos[2]};
+  // p = ((x + .5) / W, (y + .5) / H) on the normalised camera
+  px.rayD = rig_direction(cd, (x + 0.5) / (double)V.W, (y + 0.5) / (double)V.H, cd.principal[0], cd.principal[1],
+                          cd.focal[0], cd.focal[1]);
+  const size_t n = (size_t)V.W * V.H;
+  const ushort4* col = V.srcColor + (size_t)own * n;
+#pragma unroll
+  for (int ix = 0; ix < 3; ++ix) {
+#pragma unroll
+    for (int iy = 0; iy < 3; ++iy) {
+      const ushort4 q = col[(size_t)(y + iy - 1) * V.W + (x + ix - 1)];
+      px.patch[ix * 3 + iy][0] = (float)q.x;
+      px.patch[ix * 3 + iy][1] = (float)q.y;
+      px.patch[ix * 3 + iy][2] = (float)q.z;
+    }
+  }
+  const ushort4 b = V.ownBias[(size_t)own * n + (size_t)y * V.W + x];
+  px.dstBias[0] = (float)b.x;
+  px.dstBias[1] = (float)b.y;
+  px.dstBias[2] = (float)b.z;
+  const float var = V.srcVar[(size_t)own * n + (size_t)y * V.W + x];
+  px.confidence = fmaxf(var, kMinVar);
+}
+
+__device__ __forceinline__ void flush_counters(const LevelView& V, unsigned nCost, unsigned nPair) {
+  // wave-level reduction, one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    nCost += __shfl_down(nCost, off);
+    nPair += __shfl_down(nPair, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&V.counters[0], (unsigned long long)nCost);
+    atomicAdd(&V.counters[1], (unsigned long long)nPair);
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// upload conversion: interleaved BGR u16 -> ushort4
+// ----------------------------------------------------------------------------------------
+__global__ void k_bgr_to_bgrx(const uint16_t* __restrict__ in, ushort4* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    out[i] = make_ushort4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0);
+  }
+}
+
+// generateFovMasks — DerpUtil.cpp:239-276 (normalised camera: p = (x+.5, y+.5) / (W, H))
+__global__ void k_fov_mask(const Cam* __restrict__ cams, int W, int H, uint8_t* __restrict__ out) {
+  const int d = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const Cam& c = cams[d];
+  const double px = (x + 0.5) / (double)W, py = (y + 0.5) / (double)H;
+  out[(size_t)d * W * H + (size_t)y * W + x] =
+      !outside_image_circle(c, px, py, c.principal[0], c.principal[1], c.focal[0], c.focal[1]);
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) {
+    return 0;
+  }
+  while (p < 0 || p >= len) {
+    p = p < 0 ? -p : 2 * len - 2 - p;
+  }
+  return p;
+}
+
+// computeImageVariance — DerpUtil.cpp:214-237 (cv::blur 3x3 on CV_32FC3: double row sums,
+// double column sums, * 1/9 -> float; BORDER_REFLECT_101), PyramidLevel.h:232-247
+__global__ void k_variance(const ushort4* __restrict__ color, int W, int H, float* __restrict__ var) {
+  const int s = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const ushort4* img = color + (size_t)s * W * H;
+  const float scale = 1.0f / 65535.0f;
+  double sum[3] = {0, 0, 0}, sumSq[3] = {0, 0, 0};
+  const int xs[3] = {reflect101(x - 1, W), x, reflect101(x + 1, W)};
+  for (int j = -1; j <= 1; ++j) {
+    const int yy = reflect101(y + j, H);
+    double rs[3], rq[3];
+    {
+      const ushort4 q0 = img[(size_t)yy * W + xs[0]], q1 = img[(size_t)yy * W + xs[1]], q2 = img[(size_t)yy * W + xs[2]];
+      const float f0[3] = {q0.x * scale, q0.y * scale, q0.z * scale};
+      const float f1[3] = {q1.x * scale, q1.y * scale, q1.z * scale};
+      const float f2[3] = {q2.x * scale, q2.y * scale, q2.z * scale};
+      for (int c = 0; c < 3; ++c) {
+        rs[c] = (double)f0[c] + (double)f1[c] + (double)f2[c];
+        rq[c] = (double)(f0[c] * f0[c]) + (double)(f1[c] * f1[c]) + (double)(f2[c] * f2[c]);
+      }
+    }
+    for (int c = 0; c < 3; ++c) {
+      sum[c] += rs[c];
+      sumSq[c] += rq[c];
+    }
+  }
+  const double k = 1. / 9;
+  float v[3];
+  for (int c = 0; c < 3; ++c) {
+    const float mean = (float)(sum[c] * k);
+    const float meanSq = (float)(sumSq[c] * k);
+    v[c] = meanSq - mean * mean;
+  }
+  // varChannels[0]*w[2] + varChannels[1]*w[1] + varChannels[2]*w[0], kRgbWeights = {.3333,.3334,.3333}
+  const float t = v[0] * 0.3333f + v[1] * 0.3334f;
+  var[(size_t)s * W * H + (size_t)y * W + x] = t * 1.0f + v[2] * 0.3333f;
+}
+
+// colorBias = cv::blur 3x3 on CV_16UC3 (DerpUtil.cpp:208-210): exact integer sum, round(sum/9).
+// Source and destination may carry replicated rings (padIn / padOut); the blur itself uses
+// BORDER_REFLECT_101 over the image interior, and ring texels repeat the clamped interior value.
+__global__ void k_blur3_u16(const ushort4* __restrict__ in, int padIn, ushort4* __restrict__ out, int padOut, int W,
+                            int H, size_t planeIn, size_t planeOut) {
+  const int p = blockIdx.z;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  const int OW = W + 2 * padOut, OH = H + 2 * padOut;
+  if (ox >= OW || oy >= OH) {
+    return;
+  }
+  const int x = min(max(ox - padOut, 0), W - 1), y = min(max(oy - padOut, 0), H - 1);
+  const ushort4* img = in + (size_t)p * planeIn;
+  const int IW = W + 2 * padIn;
+  unsigned s0 = 0, s1 = 0, s2 = 0;
+  for (int j = -1; j <= 1; ++j) {
+    const int yy = reflect101(y + j, H) + padIn;
+    for (int i = -1; i <= 1; ++i) {
+      const int xx = reflect101(x + i, W) + padIn;
+      const ushort4 q = img[(size_t)yy * IW + xx];
+      s0 += q.x;
+      s1 += q.y;
+      s2 += q.z;
+    }
+  }
+  out[(size_t)p * planeOut + (size_t)oy * OW + ox] =
+      make_ushort4((unsigned short)((s0 + 4) / 9), (unsigned short)((s1 + 4) / 9), (unsigned short)((s2 + 4) / 9), 0);
+}
+
+// ----------------------------------------------------------------------------------------
+// precomputeProjections (Derp.cpp:955-976) -> computeWarpDstToSrc (ImageUtil.cpp:142-167).
+// projWarp(dst d, src s) lives on the SRC grid: for every src pixel, the dst pixel hit by the
+// src ray at kNearInfinity. One thread per (src, padded pixel): the ray is shared by all dsts.
+// Cameras are the level-size rescale of the normalised ones (Camera.cpp:217-223).
+// ----------------------------------------------------------------------------------------
+__global__ void k_proj_warp(LevelView V, float2* __restrict__ projWarp) {
+  const int s = blockIdx.z;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  const int OW = V.W + 2 * kPadW, OH = V.H + 2 * kPadW;
+  if (ox >= OW || oy >= OH) {
+    return;
+  }
+  const int x = min(max(ox - kPadW, 0), V.W - 1), y = min(max(oy - kPadW, 0), V.H - 1);
+  const Cam& cs = V.camsSrc[s];
+  const double W = V.W, H = V.H;
+  const double sprx = cs.principal[0] * W, spry = cs.principal[1] * H, sfx = cs.focal[0] * W, sfy = cs.focal[1] * H;
+  const double px = x + 0.5, py = y + 0.5;
+  const bool outside = outside_image_circle(cs, px, py, sprx, spry, sfx, sfy);
+  D3 rig = {0, 0, 0};
+  if (!outside) {
+    const D3 dir = rig_direction(cs, px, py, sprx, spry, sfx, sfy);
+    rig = {cs.pos[0] + dir.x * 1e4, cs.pos[1] + dir.y * 1e4, cs.pos[2] + dir.z * 1e4};
+  }
+  const size_t plane = (size_t)OW * OH;
+  const float nan = __builtin_nanf("");
+  for (int dl = 0; dl < V.D; ++dl) {
+    const int d = V.dst0 + dl;
+    const int own = V.dst2src[d];
+    if (s == own) {
+      continue;  // ids equal: all-NaN in the reference, never read (src == dst is skipped)
+    }
+    float2 val = make_float2(nan, nan);
+    if (!outside) {
+      const Cam& cd = V.camsDst[d];
+      D2 p;
+      if (sees(cd, rig, cd.principal[0] * W, cd.principal[1] * H, cd.focal[0] * W, cd.focal[1] * H, W, H, p)) {
+        val = make_float2((float)(p.x - (double)0.5f), (float)(p.y - (double)0.5f));
+      }
+    }
+    projWarp[((size_t)dl * (V.S - 1) + slot(s, own)) * plane + (size_t)oy * OW + ox] = val;
+  }
+}
+
+// cubic coefficients: imgwarp.cpp interpolateCubic, A = -0.75, x = k/32
+__device__ __forceinline__ void cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+// cvRound(float): round-half-even, INT_MIN on NaN / overflow (cvtss2si)
+__device__ __forceinline__ int cv_round(float v) {
+  if (!(v > -2147483648.0f && v < 2147483648.0f)) {
+    return (int)0x80000000;
+  }
+  return (int)rintf(v);
+}
+
+// reprojectColors (Derp.cpp:978-1003): projColor(d, s) = cv::remap(srcColor[s], projWarpInv(d, s),
+// INTER_CUBIC, BORDER_CONSTANT 0) (DerpUtil.cpp:199-205). projWarpInv is not materialised: the
+// dst-pixel ray is computed once per thread and pushed through every src (ImageUtil.cpp:142-167),
+// the float coordinate goes straight into the remap arithmetic (1/32-px fixed point, 4x4 taps,
+// float weights, saturate_cast<ushort> = round-half-even).
+__global__ void k_reproject(LevelView V, ushort4* __restrict__ projColor) {
+  const int dl = blockIdx.z;
+  const int d = V.dst0 + dl;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
+  const int OW = V.W + 2 * kPadC, OH = V.H + 2 * kPadC;
+  if (ox >= OW || oy >= OH) {
+    return;
+  }
+  const int x = min(max(ox - kPadC, 0), V.W - 1), y = min(max(oy - kPadC, 0), V.H - 1);
+  const Cam& cd = V.camsDst[d];
+  const int own = V.dst2src[d];
+  const double W = V.W, H = V.H;
+  const double dprx = cd.principal[0] * W, dpry = cd.principal[1] * H, dfx = cd.focal[0] * W, dfy = cd.focal[1] * H;
+  const double px = x + 0.5, py = y + 0.5;
+  const bool outside = outside_image_circle(cd, px, py, dprx, dpry, dfx, dfy);
+  D3 rig = {0, 0, 0};
+  if (!outside) {
+    const D3 dir = rig_direction(cd, px, py, dprx, dpry, dfx, dfy);
+    rig = {cd.pos[0] + dir.x * 1e4, cd.pos[1] + dir.y * 1e4, cd.pos[2] + dir.z * 1e4};
+  }
+  const size_t plane = (size_t)OW * OH;
+  const size_t n = (size_t)V.W * V.H;
+  for (int s = 0; s < V.S; ++s) {
+    if (s == own) {
+      continue;
+    }
+    ushort4 outv = make_ushort4(0, 0, 0, 0);  // NaN map -> (-32768,-32768) -> constant border 0
+    D2 p;
+    const Cam& cs = V.camsSrc[s];
+    if (!outside &&
+        sees(cs, rig, cs.principal[0] * W, cs.principal[1] * H, cs.focal[0] * W, cs.focal[1] * H, W, H, p)) {
+      const float mx = (float)(p.x - (double)0.5f), my = (float)(p.y - (double)0.5f);
+      const int fsx = cv_round(mx * 32.0f), fsy = cv_round(my * 32.0f);
+      const int fx = fsx & 31, fy = fsy & 31;
+      const int sx = min(max(fsx >> 5, -32768), 32767) - 1, sy = min(max(fsy >> 5, -32768), 32767) - 1;
+      float cx[4], cy[4];
+      cubic_coeffs((float)fx * (1.f / 32), cx);
+      cubic_coeffs((float)fy * (1.f / 32), cy);
+      const ushort4* img = V.srcColor + (size_t)s * n;
+      float sum[3];
+      if ((unsigned)sx < (unsigned)max(V.W - 3, 0) && (unsigned)sy < (unsigned)max(V.H - 3, 0)) {
+        float rowsum[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const ushort4* r = img + (size_t)(sy + i) * V.W + sx;
+          const ushort4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+          const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+          rowsum[i][0] = q0.x * w0 + q1.x * w1 + q2.x * w2 + q3.x * w3;
+          rowsum[i][1] = q0.y * w0 + q1.y * w1 + q2.y * w2 + q3.y * w3;
+          rowsum[i][2] = q0.z * w0 + q1.z * w1 + q2.z * w2 + q3.z * w3;
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float acc = rowsum[0][c];
+          acc += rowsum[1][c];
+          acc += rowsum[2][c];
+          acc += rowsum[3][c];
+          sum[c] = acc;
+        }
+      } else if (sx >= V.W || sx + 4 <= 0 || sy >= V.H || sy + 4 <= 0) {
+        sum[0] = sum[1] = sum[2] = 0.f;
+      } else {
+        sum[0] = sum[1] = sum[2] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const int yy = sy + i;
+          if ((unsigned)yy >= (unsigned)V.H) {
+            continue;
+          }
+          for (int j = 0; j < 4; ++j) {
+            const int xx = sx + j;
+            if ((unsigned)xx >= (unsigned)V.W) {
+              continue;
+            }
+            const ushort4 q = img[(size_t)yy * V.W + xx];
+            const float w = cy[i] * cx[j];
+            sum[0] += ((float)q.x - 0.f) * w;
+            sum[1] += ((float)q.y - 0.f) * w;
+            sum[2] += ((float)q.z - 0.f) * w;
+          }
+        }
+      }
+      const int r0 = min(max(cv_round(sum[0]), 0), 65535), r1 = min(max(cv_round(sum[1]), 0), 65535),
+                r2 = min(max(cv_round(sum[2]), 0), 65535);
+      outv = make_ushort4((unsigned short)r0, (unsigned short)r1, (unsigned short)r2, 0);
+    }
+    projColor[((size_t)dl * (V.S - 1) + slot(s, own)) * plane + (size_t)oy * OW + ox] = outv;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// brute force — Derp.cpp:230-382. Stage 1: cost / confidence for (dst, disparity i, pixel);
+// stage 2: strict-< argmin over i + fallbacks; stage 3: 1-px margin replicated from the interior.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float probe_disparity(int i, float minD, float maxD) {  // ImageUtil.cpp:100-107
+  const double fraction = (double)i / (double)(kNumDepths - 1);
+  return (float)(fraction * (double)minD + (1 - fraction) * (double)maxD);
+}
+
+__global__ void __launch_bounds__(256)
+    k_brute_costs(LevelView V, float* __restrict__ costs, float* __restrict__ confs, int tilesX, int tilesPerDst) {
+  extern __shared__ SsdPair ldsPairs[];
+  const int i = blockIdx.y;   // disparity index
+  const int dl = blockIdx.z;
+  const int d = V.dst0 + dl;
+  int x, y;
+  tile_pixel(blockIdx.x, tilesX, x, y);
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+  unsigned nCost = 0, nPair = 0;
+  if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
+    const int own = V.dst2src[d];
+    const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+    const float minDisparity = 1.0f / V.maxDepthM, maxDisparity = 1.0f / V.minDepthM;
+    const float disparity = probe_disparity(i, minDisparity, maxDisparity);
+    const bool fov = V.fovMask[(size_t)d * n + idx], fg = V.srcFg[(size_t)own * n + idx];
+    const bool closer = V.hasFg ? (V.bgDisp[(size_t)d * n + idx] < disparity) : true;
+    float2 r = make_float2(__builtin_nanf(""), __builtin_nanf(""));
+    if (fov && fg && closer) {
+      PixCtx px;
+      load_pixctx(V, d, own, x, y, px);
+      r = compute_cost(V, dl, own, px, disparity, pairs, nPair);
+      ++nCost;
+    }
+    const size_t o = ((size_t)dl * kNumDepths + i) * n + idx;
+    costs[o] = r.x;
+    confs[o] = r.y;
+  }
+  flush_counters(V, nCost, nPair);
+}
+
+__global__ void k_brute_select(LevelView V, const float* __restrict__ costs, const float* __restrict__ confs) {
+  const int dl = blockIdx.z;
+  const int d = V.dst0 + dl;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x < 1 || y < 1 || x >= V.W - 1 || y >= V.H - 1) {
+    return;
+  }
+  const int own = V.dst2src[d];
+  const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+  float* disp = V.disparity + (size_t)d * n;
+  if (!V.fovMask[(size_t)d * n + idx]) {
+    disp[idx] = __builtin_nanf("");
+    return;
+  }
+  if (!V.srcFg[(size_t)own * n + idx]) {
+    disp[idx] = V.bgDisp[(size_t)d * n + idx];
+    return;
+  }
+  float minCost = 3.402823466e+38f, minConf = 0;
+  int best = -1;
+  for (int i = 0; i < kNumDepths; ++i) {
+    const size_t o = ((size_t)dl * kNumDepths + i) * n + idx;
+    const float c = costs[o];
+    if (c < minCost) {
+      minCost = c;
+      minConf = confs[o];
+      best = i;
+    }
+  }
+  const float minDisparity = 1.0f / V.maxDepthM, maxDisparity = 1.0f / V.minDepthM;
+  if (best == -1) {
+    atomicAdd(&V.counters[2], 1ull);  // "Insufficient coverage" warning / CHECK in the reference
+    disp[idx] = minDisparity;
+  } else {
+    disp[idx] = probe_disparity(best, minDisparity, maxDisparity);
+  }
+  V.cost[(size_t)d * n + idx] = minCost;
+  V.confidence[(size_t)d * n + idx] = minConf;
+}
+
+__global__ void k_brute_margin(LevelView V) {
+  const int d = V.dst0 + blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= V.W || y >= V.H) {
+    return;
+  }
+  if (!(x < 1 || x >= V.W - 1 || y < 1 || y >= V.H - 1)) {
+    return;
+  }
+  const int own = V.dst2src[d];
+  const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+  if (!V.srcFg[(size_t)own * n + idx]) {
+    V.disparity[(size_t)d * n + idx] = V.bgDisp[(size_t)d * n + idx];
+    return;
+  }
+  const int yy = min(max(y, 1), V.H - 2), xx = min(max(x, 1), V.W - 2);
+  const size_t src = (size_t)yy * V.W + xx;
+  V.disparity[(size_t)d * n + idx] = V.disparity[(size_t)d * n + src];
+  V.cost[(size_t)d * n + idx] = V.cost[(size_t)d * n + src];
+  V.confidence[(size_t)d * n + idx] = V.confidence[(size_t)d * n + src];
+}
+
+// ----------------------------------------------------------------------------------------
+// random proposals — Derp.cpp:750-873. The reference walks each row with one engine seeded
+// y * level; a pixel's draws start at numProposals * (#gated-in pixels to its left).
+// k_row_rank computes that count; k_random_proposals jumps the LCG there.
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ bool random_gate(const LevelView& V, int d, int own, size_t idx) {
+  const size_t n = (size_t)V.W * V.H;
+  if (!V.fovMask[(size_t)d * n + idx] || !V.srcFg[(size_t)own * n + idx]) {
+    return false;
+  }
+  const float varHighDev = 0.1f * V.varHighThresh;  // kRandomPropHighVarDeviation
+  const float thresh = fmaxf(varHighDev, V.varNoiseFloor);
+  return !(V.srcVar[(size_t)own * n + idx] < thresh);
+}
+
+__global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__ rank) {
+  __shared__ int partial[256];
+  const int d = V.dst0 + blockIdx.y, y = blockIdx.x + 1;
+  const int own = V.dst2src[d];
+  const size_t n = (size_t)V.W * V.H;
+  const int inner = V.W - 2;
+  const int per = (inner + 255) / 256;
+  const int x0 = 1 + threadIdx.x * per, x1 = min(x0 + per, V.W - 1);
+  int cnt = 0;
+  for (int x = x0; x < x1; ++x) {
+    cnt += random_gate(V, d, own, (size_t)y * V.W + x);
+  }
+  partial[threadIdx.x] = cnt;
+  __syncthreads();
+  // exclusive scan of 256 partials (Hillis-Steele)
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = (threadIdx.x >= off) ? partial[threadIdx.x - off] : 0;
+    __syncthreads();
+    partial[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = partial[threadIdx.x] - cnt;
+  for (int x = x0; x < x1; ++x) {
+    rank[(size_t)d * n + (size_t)y * V.W + x] = run;
+    run += random_gate(V, d, own, (size_t)y * V.W + x);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+    k_random_proposals(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
+  extern __shared__ SsdPair ldsPairs[];
+  const int dl = blockIdx.y;
+  const int d = V.dst0 + dl;
+  int x, y;
+  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x), tilesX, x, y);
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+  unsigned nCost = 0, nPair = 0;
+  if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
+    const int own = V.dst2src[d];
+    const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+    float* disp = V.disparity + (size_t)d * n;
+    if (V.fovMask[(size_t)d * n + idx]) {
+      if (!V.srcFg[(size_t)own * n + idx]) {
+        disp[idx] = V.bgDisp[(size_t)d * n + idx];
+      } else if (random_gate(V, d, own, idx)) {
+        PixCtx px;
+        load_pixctx(V, d, own, x, y, px);
+        float currDisp = disp[idx];
+        float2 cur = compute_cost(V, dl, own, px, currDisp, pairs, nPair);
+        ++nCost;
+        float currCost = cur.x, currConf = cur.y;
+        const float costThresh = fminf(0.5f * currCost, 5.0f);  // kRandomPropMaxCost
+        const float minDisp = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : (1.0f / V.maxDepthM);
+        const float maxDisp = 1.0f / V.minDepthM;
+        float amplitude = (maxDisp - minDisp) / 2.0f;
+        uint32_t state = minstd_jump(minstd_seed(y * V.level),
+                                     (uint64_t)V.randomProposals * (uint64_t)rank[(size_t)d * n + idx]);
+        for (int i = 0; i < V.randomProposals; ++i) {
+          const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
+          const float propDisp = minstd_uniform(state, lo, hi);
+          const float2 pr = compute_cost(V, dl, own, px, propDisp, pairs, nPair);
+          ++nCost;
+          if (pr.x < currCost && pr.x < costThresh) {
+            currCost = pr.x;
+            currDisp = propDisp;
+            currConf = pr.y;
+            amplitude /= 2.0f;
+          }
+        }
+        disp[idx] = currDisp;
+        V.cost[(size_t)d * n + idx] = currCost;
+        V.confidence[(size_t)d * n + idx] = currConf;
+      }
+    }
+  }
+  flush_counters(V, nCost, nPair);
+}
+
+// ----------------------------------------------------------------------------------------
+// ping-pong propagation — Derp.cpp:403-538. Jacobi: reads disparity, writes dispRes / costRes.
+// ----------------------------------------------------------------------------------------
+__constant__ int kCandidates[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-2, -2}, {2, -2}, {-2, 2}, {2, 2}};
+
+__global__ void __launch_bounds__(256)
+    k_ping_pong(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
+                float* __restrict__ costRes, int tilesX, int tilesPerDst) {
+  extern __shared__ SsdPair ldsPairs[];
+  const int dl = blockIdx.y;
+  const int d = V.dst0 + dl;
+  int x, y;
+  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x), tilesX, x, y);
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+  unsigned nCost = 0, nPair = 0;
+  if (x < V.W && y < V.H) {
+    const int own = V.dst2src[d];
+    const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+    const float* disp = V.disparity + (size_t)d * n;
+    const uint8_t* fov = V.fovMask + (size_t)d * n;
+    float outDisp = disp[idx];
+    float outCost = __builtin_inff();
+    const bool interior = x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1;
+    if (interior && fov[idx]) {
+      if (!V.srcFg[(size_t)own * n + idx]) {
+        outDisp = V.bgDisp[(size_t)d * n + idx];
+      } else if (!(V.srcVar[(size_t)own * n + idx] < V.varNoiseFloor)) {
+        PixCtx px;
+        load_pixctx(V, d, own, x, y, px);
+        float bestCost = __builtin_inff();
+        float bestDisp = outDisp;
+        const float bg = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : 0.f;
+        for (int k = 0; k < 9; ++k) {
+          const int xx = min(max(x + kCandidates[k][0], 0), V.W - 1);
+          const int yy = min(max(y + kCandidates[k][1], 0), V.H - 1);
+          const size_t j = (size_t)yy * V.W + xx;
+          if (fov[j]) {
+            const float cand = disp[j];
+            if (cand >= bg && changed[(size_t)d * n + j]) {
+              const float2 r = compute_cost(V, dl, own, px, cand, pairs, nPair);
+              ++nCost;
+              if (r.x < bestCost) {
+                bestCost = r.x;
+                bestDisp = cand;
+              }
+            }
+          }
+        }
+        outDisp = bestDisp;
+        outCost = bestCost;
+      }
+    }
+    dispRes[(size_t)d * n + idx] = outDisp;
+    costRes[(size_t)d * n + idx] = outCost;
+  }
+  flush_counters(V, nCost, nPair);
+}
+
+// changed = disp != dispRes; dispRes -> disp; costRes -> cost (Derp.cpp:527-529)
+__global__ void k_ping_pong_commit(float* __restrict__ disp, float* __restrict__ cost, const float* __restrict__ dispRes,
+                                   const float* __restrict__ costRes, uint8_t* __restrict__ changed, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float a = disp[i], b = dispRes[i];
+    changed[i] = (a != b);
+    disp[i] = b;
+    cost[i] = costRes[i];
+  }
+}
+
+// cost map of a caller-supplied disparity image (test hook over compute_cost)
+__global__ void __launch_bounds__(256)
+    k_cost_map(LevelView V, int d, const float* __restrict__ dispIn, float* __restrict__ costOut,
+               float* __restrict__ confOut, int tilesX) {
+  extern __shared__ SsdPair ldsPairs[];
+  const int dl = d - V.dst0;
+  int x, y;
+  tile_pixel(blockIdx.x, tilesX, x, y);
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+  unsigned nCost = 0, nPair = 0;
+  if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
+    const int own = V.dst2src[d];
+    PixCtx px;
+    load_pixctx(V, d, own, x, y, px);
+    const float2 r = compute_cost(V, dl, own, px, dispIn[(size_t)y * V.W + x], pairs, nPair);
+    ++nCost;
+    costOut[(size_t)y * V.W + x] = r.x;
+    confOut[(size_t)y * V.W + x] = r.y;
+  }
+  flush_counters(V, nCost, nPair);
+}
+
+// ----------------------------------------------------------------------------------------
+// filters
+// ----------------------------------------------------------------------------------------
+// expf as the reference's libm computes it (correctly rounded for all practical purposes):
+// evaluate in fp64, round once to fp32.
+__device__ __forceinline__ float expf_cr(float x) {
+  return (float)exp((double)x);
+}
+
+// generalizedJointBilateralFilter<float, Vec3w> — TemporalBilateralFilter.h:39-124.
+// guide = BGRX u16; mask = fov & fg; result written where `copyMask` (or everywhere if null).
+__global__ void k_joint_bilateral_u16(const float* __restrict__ image, const ushort4* __restrict__ guide,
+                                      const uint8_t* __restrict__ mask, const uint8_t* __restrict__ copyMask, int W,
+                                      int H, int radius, float sigma, float weight0, float weight1, float weight2,
+                                      float* __restrict__ out, size_t planeStride, size_t guideStride,
+                                      const int* __restrict__ guideIndex) {
+  const int p = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const size_t idx = (size_t)y * W + x;
+  const float* img = image + (size_t)p * planeStride;
+  const uint8_t* m = mask + (size_t)p * planeStride;
+  const ushort4* g = guide + (size_t)(guideIndex ? guideIndex[p] : p) * guideStride;
+  float result = img[idx];
+  if (m[idx]) {
+    const ushort4 gc = g[idx];
+    const float factor = 1 / 65535.0f;
+    const float g0 = gc.x * factor, g1 = gc.y * factor, g2 = gc.z * factor;
+    const float denom = 2.0f * (sigma * sigma);
+    float sumWeight = 0.f, weightedAvg = 0.f;
+    for (int v = -radius; v <= radius; ++v) {
+      const int sy = min(max(y + v, 0), H - 1);
+      for (int u = -radius; u <= radius; ++u) {
+        const int sx = min(max(x + u, 0), W - 1);
+        const size_t j = (size_t)sy * W + sx;
+        if (!m[j]) {
+          continue;
+        }
+        const ushort4 nb = g[j];
+        const float d0 = g0 - nb.x * factor, d1 = g1 - nb.y * factor, d2 = g2 - nb.z * factor;
+        const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
+        const float weight = expf_cr((-colorDiffSq / 3.0f) / denom);
+        sumWeight += weight;
+        weightedAvg += weight * img[j];
+      }
+    }
+    if (sumWeight != 0.0f) {
+      result = weightedAvg / sumWeight;
+    }
+  }
+  if (!copyMask || copyMask[(size_t)(guideIndex ? guideIndex[p] : p) * guideStride + idx]) {
+    out[(size_t)p * planeStride + idx] = result;
+  } else {
+    out[(size_t)p * planeStride + idx] = img[idx];
+  }
+}
+
+// generalizedJointBilateralFilter<float, Vec3f> (UpsampleDisparity.cpp:109-128), guide = 3 floats
+__global__ void k_joint_bilateral_f32(const float* __restrict__ image, const float* __restrict__ guide,
+                                      const uint8_t* __restrict__ mask, int W, int H, int radius, float sigma,
+                                      float weight0, float weight1, float weight2, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const size_t idx = (size_t)y * W + x;
+  float result = image[idx];
+  if (mask[idx]) {
+    const float factor = 1 / 1.0f;
+    const float g0 = guide[3 * idx] * factor, g1 = guide[3 * idx + 1] * factor, g2 = guide[3 * idx + 2] * factor;
+    const float denom = 2.0f * (sigma * sigma);
+    float sumWeight = 0.f, weightedAvg = 0.f;
+    for (int v = -radius; v <= radius; ++v) {
+      const int sy = min(max(y + v, 0), H - 1);
+      for (int u = -radius; u <= radius; ++u) {
+        const int sx = min(max(x + u, 0), W - 1);
+        const size_t j = (size_t)sy * W + sx;
+        if (!mask[j]) {
+          continue;
+        }
+        const float d0 = g0 - guide[3 * j] * factor, d1 = g1 - guide[3 * j + 1] * factor,
+                    d2 = g2 - guide[3 * j + 2] * factor;
+        const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
+        const float weight = expf_cr((-colorDiffSq / 3.0f) / denom);
+        sumWeight += weight;
+        weightedAvg += weight * image[j];
+      }
+    }
+    if (sumWeight != 0.0f) {
+      result = weightedAvg / sumWeight;
+    }
+  }
+  out[idx] = result;
+}
+
+// maskedMedianBlur radius 1 — CvUtil.h:336-385; optional fused maskFov (Derp.cpp:940-951)
+__global__ void k_masked_median(const float* __restrict__ image, const float* __restrict__ background,
+                                const uint8_t* __restrict__ mask, int W, int H, int radius, float* __restrict__ out,
+                                size_t planeStride, const uint8_t* __restrict__ fovForNan) {
+  const int p = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const size_t idx = (size_t)y * W + x;
+  const float* img = image + (size_t)p * planeStride;
+  const uint8_t* m = mask + (size_t)p * planeStride;
+  float result = 0.0f;
+  if (!m[idx]) {
+    if (background) {
+      result = background[(size_t)p * planeStride + idx];
+    }
+  } else {
+    float vals[25];
+    int cnt = 0;
+    for (int yy = y - radius; yy <= y + radius; ++yy) {
+      for (int xx = x - radius; xx <= x + radius; ++xx) {
+        if (0 > yy || yy >= H || 0 > xx || xx >= W) {
+          continue;
+        }
+        const size_t j = (size_t)yy * W + xx;
+        if (!m[j]) {
+          continue;
+        }
+        const float v = img[j];
+        if (isnan(v) || v == 0) {
+          continue;
+        }
+        // insertion into sorted order (values only: the median does not depend on the sort used)
+        int k = cnt++;
+        while (k > 0 && vals[k - 1] > v) {
+          vals[k] = vals[k - 1];
+          --k;
+        }
+        vals[k] = v;
+      }
+    }
+    if (cnt > 0) {
+      const int h = cnt / 2;
+      if (cnt % 2 == 1) {
+        result = vals[h];
+      } else {
+        result = (float)(((double)(vals[h - 1] + vals[h])) / 2.0);
+      }
+    }
+  }
+  if (fovForNan && !fovForNan[(size_t)p * planeStride + idx]) {
+    result = __builtin_nanf("");
+  }
+  out[(size_t)p * planeStride + idx] = result;
+}
+
+__global__ void k_mask_fov(float* __restrict__ disp, const uint8_t* __restrict__ fov, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    if (!fov[i]) {
+      disp[i] = __builtin_nanf("");
+    }
+  }
+}
+
+__global__ void k_and_masks(const uint8_t* fov, const uint8_t* srcFg, const int* __restrict__ dst2src, int dst0,
+                            size_t n, uint8_t* out) {
+  const int d = dst0 + blockIdx.y;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    out[(size_t)d * n + i] = fov[(size_t)d * n + i] & srcFg[(size_t)dst2src[d] * n + i];
+  }
+}
+
+// ----------------------------------------------------------------------------------------
+// upsample — UpsampleDisparityLib.cpp:98-147
+// ----------------------------------------------------------------------------------------
+// Lanczos4 coefficients are computed on the host (resize.cpp interpolateLanczos4 uses libm
+// sin/cos in fp64): xofs/alpha per output column, yofs/beta per output row.
+__global__ void k_lanczos_h(const float* __restrict__ in, int SW, int SH, int DW, const int* __restrict__ xofs,
+                            const float* __restrict__ alpha, float* __restrict__ tmp, size_t inStride,
+                            size_t tmpStride) {
+  const int p = blockIdx.z;
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (dx >= DW || y >= SH) {
+    return;
+  }
+  const float* S = in + (size_t)p * inStride + (size_t)y * SW;
+  const float* a = alpha + (size_t)dx * 8;
+  const int sx = xofs[dx] - 3;
+  float v = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int sxj = min(max(sx + j, 0), SW - 1);
+    float sv = S[sxj];
+    if (sv != sv) {
+      sv = 1e-4f;  // OpenCV doesn't handle NaNs: NaN -> minDisp (UpsampleDisparityLib.cpp:141-144)
+    }
+    v += sv * a[j];
+  }
+  tmp[(size_t)p * tmpStride + (size_t)y * DW + dx] = v;
+}
+__global__ void k_lanczos_v(const float* __restrict__ tmp, int SH, int DW, int DH, const int* __restrict__ yofs,
+                            const float* __restrict__ beta, float* __restrict__ out, size_t tmpStride,
+                            size_t outStride) {
+  const int p = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= DW || dy >= DH) {
+    return;
+  }
+  const float* T = tmp + (size_t)p * tmpStride;
+  const float* b = beta + (size_t)dy * 8;
+  const int sy = yofs[dy] - 3;
+  float r[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int syk = min(max(sy + k, 0), SH - 1);
+    r[k] = T[(size_t)syk * DW + x];
+  }
+  out[(size_t)p * outStride + (size_t)dy * DW + x] =
+      r[0] * b[0] + r[1] * b[1] + r[2] * b[2] + r[3] * b[3] + r[4] * b[4] + r[5] * b[5] + r[6] * b[6] + r[7] * b[7];
+}
+
+// masked path, steps 1-3: coarse value outside (fov & fg) -> NaN, INTER_NEAREST, NaN outside maskUp
+__global__ void k_upsample_nearest_masked(const float* __restrict__ in, const uint8_t* __restrict__ mask, int SW,
+                                          int SH, const uint8_t* __restrict__ maskUp, int DW, int DH,
+                                          float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= DW || y >= DH) {
+    return;
+  }
+  const double ifx = (double)SW / DW, ify = (double)SH / DH;
+  const int sx = min((int)floor(x * ifx), SW - 1), sy = min((int)floor(y * ify), SH - 1);
+  float v = in[(size_t)sy * SW + sx];
+  if (!mask[(size_t)sy * SW + sx] || !maskUp[(size_t)y * DW + x]) {
+    v = __builtin_nanf("");
+  }
+  out[(size_t)y * DW + x] = v;
+}
+// step 4: replaceNans — first value > 0 along the clockwise spiral (host-generated offsets)
+__global__ void k_spiral_fill(const float* __restrict__ dispUp, const float* __restrict__ bgUp,
+                              const uint8_t* __restrict__ maskUp, int W, int H, const int2* __restrict__ spiral,
+                              int nSpiral, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const size_t idx = (size_t)y * W + x;
+  float v = dispUp[idx];
+  if (maskUp[idx] && !(v > 0)) {
+    for (int k = 0; k < nSpiral; ++k) {
+      const int xx = min(max(x + spiral[k].x, 0), W - 1), yy = min(max(y + spiral[k].y, 0), H - 1);
+      const float c = dispUp[(size_t)yy * W + xx];
+      if (c > 0) {
+        v = c;
+        break;
+      }
+    }
+  }
+  if (isnan(v) || v == 0) {
+    v = bgUp[idx];
+  }
+  out[idx] = v;
+}
+
+// ----------------------------------------------------------------------------------------
+// temporal joint bilateral — TemporalBilateralFilter.h:126-172 (quirks kept: accumulates the
+// CENTRE pixel of frame t, int colour difference / 65535.f, no sumWeight == 0 guard)
+// ----------------------------------------------------------------------------------------
+struct TemporalFrames {
+  const ushort4* guides[8];
+  const float* images[8];
+  const uint8_t* masks[8];
+  int n;
+};
+__global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, float sigma, int radius, float weight0,
+                           float weight1, float weight2, float* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const size_t idx = (size_t)y * W + x;
+  if (!F.masks[frameOffset][idx]) {
+    out[idx] = F.images[frameOffset][idx];
+    return;
+  }
+  const ushort4 ref = F.guides[frameOffset][idx];
+  const float sig2 = sigma * sigma;
+  float weightedSumPix = 0.f, sumWeight = 0.f;
+  for (int t = 0; t < F.n; ++t) {
+    const float centre = F.images[t][idx];
+    for (int u = -radius; u <= radius; ++u) {
+      const int sx = min(max(x + u, 0), W - 1);
+      for (int v = -radius; v <= radius; ++v) {
+        const int sy = min(max(y + v, 0), H - 1);
+        const size_t j = (size_t)sy * W + sx;
+        if (!F.masks[t][j]) {
+          continue;
+        }
+        const ushort4 sc = F.guides[t][j];
+        const float e0 = (float)((int)ref.x - (int)sc.x) / 65535.0f;
+        const float e1 = (float)((int)ref.y - (int)sc.y) / 65535.0f;
+        const float e2 = (float)((int)ref.z - (int)sc.z) / 65535.0f;
+        const float weightedDiff = weight0 * (e0 * e0) + weight1 * (e1 * e1) + weight2 * (e2 * e2);
+        const float weight = expf_cr(-weightedDiff / sig2);
+        weightedSumPix += centre * weight;
+        sumWeight += weight;
+      }
+    }
+  }
+  out[idx] = weightedSumPix / sumWeight;
+}
+
+}  // namespace derp

@@ -1,0 +1,372 @@
+"""ctypes binding of the C-ABI in include/derp_hip.h (libderp_hip.so, built in-tree).
+
+Plumbing only: every computation happens in the HIP library. There is no CPU fallback —
+`Derp(...)` raises when the library or a gfx950 device is missing.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libderp_hip.so")
+CAM_TYPES = {"FTHETA": 0, "RECTILINEAR": 1, "EQUISOLID": 2, "ORTHOGRAPHIC": 3}
+
+STAGES = ["fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject", "proj_bias", "brute_force",
+          "random_proposals", "ping_pong", "bilateral", "median", "mask_fov"]
+
+
+class CameraDesc(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("has_principal", C.c_int32), ("has_distortion", C.c_int32), ("has_fov", C.c_int32),
+        ("origin", C.c_double * 3), ("forward", C.c_double * 3), ("up", C.c_double * 3), ("right", C.c_double * 3),
+        ("resolution", C.c_double * 2), ("focal", C.c_double * 2), ("principal", C.c_double * 2),
+        ("distortion", C.c_double * 3), ("fov", C.c_double), ("id", C.c_char * 64),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("min_depth_m", C.c_float), ("max_depth_m", C.c_float), ("var_noise_floor", C.c_float),
+        ("var_high_thresh", C.c_float), ("random_proposals", C.c_int32), ("ping_pong_iterations", C.c_int32),
+        ("mismatches_start_level", C.c_int32), ("do_bilateral_filter", C.c_int32), ("do_median_filter", C.c_int32),
+        ("use_foreground_masks", C.c_int32), ("partial_coverage", C.c_int32), ("rebuild_warp_tables", C.c_int32),
+    ]
+
+
+# every symbol include/derp_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "derp_options_default", "derp_create", "derp_destroy", "derp_last_error", "derp_set_options", "derp_set_pyramid",
+    "derp_upload_color", "derp_upload_foreground_mask", "derp_upload_background_disparity", "derp_upload_disparity",
+    "derp_process_level", "derp_process_pyramid", "derp_synchronize", "derp_download_disparity", "derp_download_cost",
+    "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
+    "derp_stage_ping_pong", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
+    "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
+    "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
+    "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
+    "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query",
+    "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libderp_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the depth path."
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _lib.derp_last_error.restype = C.c_char_p
+        _lib.derp_last_error.argtypes = [C.c_void_p]
+        _lib.derp_host_minstd_uniform.restype = C.c_float
+        _lib.derp_host_minstd_uniform.argtypes = [C.c_int, C.c_uint64, C.c_float, C.c_float]
+    return _lib
+
+
+def camera_desc(cam):
+    j = CameraDesc()
+    j.type = CAM_TYPES[cam["type"]]
+    for k in ("origin", "forward", "up", "right", "resolution", "focal"):
+        for i, v in enumerate(cam[k]):
+            getattr(j, k)[i] = float(v)
+    j.has_principal = int("principal" in cam)
+    if "principal" in cam:
+        j.principal[0], j.principal[1] = map(float, cam["principal"])
+    j.has_distortion = int("distortion" in cam)
+    if "distortion" in cam:
+        d = list(cam["distortion"]) + [0.0] * (3 - len(cam["distortion"]))
+        for i in range(3):
+            j.distortion[i] = float(d[i])
+    j.has_fov = int("fov" in cam)
+    if "fov" in cam:
+        j.fov = float(cam["fov"])
+    j.id = cam["id"].encode()
+    return j
+
+
+def filter_destinations(cams, destinations):
+    """image_util::filterDestinations (source/util/ImageUtil.cpp:110-125)."""
+    if not destinations:
+        return list(cams)
+    out = []
+    for dest in destinations.split(","):
+        for cam in cams:
+            if cam["id"] == dest:
+                out.append(cam)
+    return out
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DerpError(RuntimeError):
+    pass
+
+
+class Derp:
+    """One context per GPU (derp_create .. derp_destroy)."""
+
+    def __init__(self, cams_src, cams_dst=None, device=0, **options):
+        cams_dst = cams_src if cams_dst is None else cams_dst
+        self.cams_src, self.cams_dst = list(cams_src), list(cams_dst)
+        self.S, self.D = len(self.cams_src), len(self.cams_dst)
+        a = (CameraDesc * self.S)(*[camera_desc(c) for c in self.cams_src])
+        b = (CameraDesc * self.D)(*[camera_desc(c) for c in self.cams_dst])
+        h = C.c_void_p()
+        if lib().derp_create(C.byref(h), device, a, self.S, b, self.D):
+            raise DerpError(lib().derp_last_error(None).decode())
+        self.h = h
+        self.sizes = None
+        self.opt = Options()
+        lib().derp_options_default(C.byref(self.opt))
+        self.set_options(**options)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().derp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise DerpError(lib().derp_last_error(self.h).decode())
+
+    def set_options(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(self.opt, k):
+                raise KeyError(k)
+            setattr(self.opt, k, type(getattr(self.opt, k))(v))
+        self._ck(lib().derp_set_options(self.h, C.byref(self.opt)))
+
+    def set_pyramid(self, sizes, width_full, height_full):
+        self.sizes = list(sizes)
+        w = (C.c_int * len(sizes))(*[s[0] for s in sizes])
+        h = (C.c_int * len(sizes))(*[s[1] for s in sizes])
+        self._ck(lib().derp_set_pyramid(self.h, len(sizes), w, h, width_full, height_full))
+
+    def _shape(self, level):
+        w, h = self.sizes[level]
+        return h, w
+
+    def upload_color(self, level, s, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint16)
+        assert bgr.shape == self._shape(level) + (3,)
+        self._ck(lib().derp_upload_color(self.h, level, s, _p(bgr)))
+
+    def upload_foreground_mask(self, level, s, mask):
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        assert mask.shape == self._shape(level)
+        self._ck(lib().derp_upload_foreground_mask(self.h, level, s, _p(mask)))
+
+    def upload_background_disparity(self, level, d, disp):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        assert disp.shape == self._shape(level)
+        self._ck(lib().derp_upload_background_disparity(self.h, level, d, _p(disp)))
+
+    def upload_disparity(self, level, d, disp):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        assert disp.shape == self._shape(level)
+        self._ck(lib().derp_upload_disparity(self.h, level, d, _p(disp)))
+
+    def upload_frame(self, frame):
+        """frame: dict from synth.make_frame (color[level][cam], optional masks / bg_disp)."""
+        for level in range(len(self.sizes)):
+            for s in range(self.S):
+                self.upload_color(level, s, frame["color"][level][s])
+                if frame.get("masks"):
+                    self.upload_foreground_mask(level, s, frame["masks"][level][s])
+            if frame.get("bg_disp"):
+                for d in range(self.D):
+                    self.upload_background_disparity(level, d, frame["bg_disp"][level][self._dst_src(d)])
+
+    def _dst_src(self, d):
+        ids = [c["id"] for c in self.cams_src]
+        return ids.index(self.cams_dst[d]["id"])
+
+    def process_level(self, level):
+        self._ck(lib().derp_process_level(self.h, level))
+
+    def process_pyramid(self, level_start=None, level_end=0):
+        level_start = len(self.sizes) - 1 if level_start is None else level_start
+        self._ck(lib().derp_process_pyramid(self.h, level_start, level_end))
+
+    def synchronize(self):
+        self._ck(lib().derp_synchronize(self.h))
+
+    def download_disparity(self, level, d):
+        out = np.zeros(self._shape(level), dtype=np.float32)
+        self._ck(lib().derp_download_disparity(self.h, level, d, _p(out)))
+        return out
+
+    def download_cost(self, level, d):
+        cost = np.zeros(self._shape(level), dtype=np.float32)
+        conf = np.zeros(self._shape(level), dtype=np.float32)
+        self._ck(lib().derp_download_cost(self.h, d, _p(cost), _p(conf)))
+        return cost, conf
+
+    # ---- stage-level
+    def level_begin(self, level):
+        self._cur = level
+        self._ck(lib().derp_level_begin(self.h, level))
+
+    def stage(self, name):
+        fn = {
+            "reproject_colors": "derp_stage_reproject_colors", "brute_force": "derp_stage_brute_force",
+            "random_proposals": "derp_stage_random_proposals", "ping_pong": "derp_stage_ping_pong",
+            "bilateral": "derp_stage_bilateral_filter", "median": "derp_stage_median_filter",
+            "mask_fov": "derp_stage_mask_fov", "end": "derp_level_end",
+        }[name]
+        self._ck(getattr(lib(), fn)(self.h))
+
+    def set_level_disparity(self, d, disp):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        self._ck(lib().derp_set_level_disparity(self.h, d, _p(disp)))
+
+    def get_level_disparity(self, d):
+        out = np.zeros(self._shape(self._cur), dtype=np.float32)
+        self._ck(lib().derp_get_level_disparity(self.h, d, _p(out)))
+        return out
+
+    def cost_map(self, d, disp):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        cost = np.zeros(self._shape(self._cur), dtype=np.float32)
+        conf = np.zeros(self._shape(self._cur), dtype=np.float32)
+        self._ck(lib().derp_cost_map(self.h, d, _p(disp), _p(cost), _p(conf)))
+        return cost, conf
+
+    def debug(self, d, s, which):
+        h, w = self._shape(self._cur)
+        spec = {"warp": (0, (h, w, 2), np.float32), "color": (2, (h, w, 3), np.uint16),
+                "bias": (3, (h, w, 3), np.uint16), "variance": (4, (h, w), np.float32),
+                "fov": (5, (h, w), np.uint8)}[which]
+        out = np.zeros(spec[1], dtype=spec[2])
+        self._ck(lib().derp_debug_download(self.h, d, s, spec[0], _p(out)))
+        return out
+
+    # ---- sibling kernels
+    def upsample_disparity(self, d, disp, w_up, h_up, bg_up=None, fg=None, fg_up=None):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        h, w = disp.shape
+        use = fg is not None
+        out = np.zeros((h_up, w_up), dtype=np.float32)
+        if use:
+            bg_up = np.ascontiguousarray(bg_up, dtype=np.float32)
+            fg = np.ascontiguousarray(fg, dtype=np.uint8)
+            fg_up = np.ascontiguousarray(fg_up, dtype=np.uint8)
+        self._ck(lib().derp_upsample_disparity(self.h, d, _p(disp), w, h, _p(bg_up) if use else None,
+                                               _p(fg) if use else None, _p(fg_up) if use else None, w_up, h_up,
+                                               int(use), _p(out)))
+        return out
+
+    def joint_bilateral_u16(self, image, guide, mask, radius, sigma, w0, w1, w2):
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        guide = np.ascontiguousarray(guide, dtype=np.uint16)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = image.shape
+        out = np.zeros_like(image)
+        self._ck(lib().derp_joint_bilateral_u16(self.h, _p(image), _p(guide), _p(mask), w, h, radius, C.c_float(sigma),
+                                                C.c_float(w0), C.c_float(w1), C.c_float(w2), _p(out)))
+        return out
+
+    def joint_bilateral_f32(self, image, guide, mask, radius, sigma, w0, w1, w2):
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        guide = np.ascontiguousarray(guide, dtype=np.float32)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = image.shape
+        out = np.zeros_like(image)
+        self._ck(lib().derp_joint_bilateral_f32(self.h, _p(image), _p(guide), _p(mask), w, h, radius, C.c_float(sigma),
+                                                C.c_float(w0), C.c_float(w1), C.c_float(w2), _p(out)))
+        return out
+
+    def masked_median(self, image, background, mask, radius=1):
+        image = np.ascontiguousarray(image, dtype=np.float32)
+        background = None if background is None else np.ascontiguousarray(background, dtype=np.float32)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        h, w = image.shape
+        out = np.zeros_like(image)
+        self._ck(lib().derp_masked_median(self.h, _p(image), _p(background), _p(mask), w, h, radius, _p(out)))
+        return out
+
+    def temporal_filter(self, guides, images, masks, frame_offset, sigma, radius, w0, w1, w2):
+        n = len(guides)
+        guides = [np.ascontiguousarray(g, dtype=np.uint16) for g in guides]
+        images = [np.ascontiguousarray(g, dtype=np.float32) for g in images]
+        masks = [np.ascontiguousarray(g, dtype=np.uint8) for g in masks]
+        h, w = images[0].shape
+        gp = (C.c_void_p * n)(*[g.ctypes.data for g in guides])
+        ip = (C.c_void_p * n)(*[g.ctypes.data for g in images])
+        mp = (C.c_void_p * n)(*[g.ctypes.data for g in masks])
+        out = np.zeros((h, w), dtype=np.float32)
+        self._ck(lib().derp_temporal_filter(self.h, gp, ip, mp, n, w, h, frame_offset, C.c_float(sigma), radius,
+                                            C.c_float(w0), C.c_float(w1), C.c_float(w2), _p(out)))
+        return out
+
+    def temporal_filter_dev(self, guide_ptrs, disp_ptrs, mask_ptrs, w, h, frame_offset, sigma, radius, w0, w1, w2,
+                            out_ptr):
+        n = len(guide_ptrs)
+        gp = (C.c_void_p * n)(*guide_ptrs)
+        ip = (C.c_void_p * n)(*disp_ptrs)
+        mp = (C.c_void_p * n)(*mask_ptrs)
+        self._ck(lib().derp_temporal_filter_dev(self.h, gp, ip, mp, n, w, h, frame_offset, C.c_float(sigma), radius,
+                                                C.c_float(w0), C.c_float(w1), C.c_float(w2), C.c_void_p(out_ptr)))
+
+    def dev_disparity(self, level, d):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(lib().derp_dev_disparity(self.h, level, d, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def dev_color(self, level, s):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(lib().derp_dev_color(self.h, level, s, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def dev_mask(self, level, d):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(lib().derp_dev_mask(self.h, level, d, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    # ---- measurement
+    def counters(self):
+        a, b, i = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._ck(lib().derp_get_counters(self.h, C.byref(a), C.byref(b), C.byref(i)))
+        return dict(n_cost=a.value, n_pair=b.value, insufficient=i.value)
+
+    def reset_counters(self):
+        self._ck(lib().derp_reset_counters(self.h))
+
+    def profile_enable(self, on=True):
+        self._ck(lib().derp_profile_enable(self.h, int(on)))
+
+    def profile_reset(self):
+        self._ck(lib().derp_profile_reset(self.h))
+
+    def profile_query(self, stage, level=-1):
+        ms, n = C.c_double(), C.c_int()
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(lib().derp_profile_query(self.h, stage.encode(), level, C.byref(ms), C.byref(n), C.byref(a), C.byref(b)))
+        return dict(ms=ms.value, launches=n.value, n_cost=a.value, n_pair=b.value)
+
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        self._ck(lib().derp_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+
+def host_nth_element_pairs(pairs, nth):
+    p = np.ascontiguousarray(pairs, dtype=np.float32).copy()
+    lib().derp_host_nth_element_pairs(_p(p), len(p), nth)
+    return p
+
+
+def host_minstd_uniform(seed, draw_index, a, b):
+    return lib().derp_host_minstd_uniform(seed, draw_index, C.c_float(a), C.c_float(b))

@@ -1,0 +1,150 @@
+"""On-disk formats of the depth path, numpy + zlib only.
+
+PFM exactly as cv_util::writeCvMat32FC1ToPFM / readCvMat32FC1FromPFM do it
+(source/util/CvUtil.cpp:39-73): header "Pf\\n<W> <H>\\n-1.0\\n", raw little-endian float32 rows
+written TOP-to-bottom (no flip). PNG: 8/16-bit gray / RGB(A), returned in OpenCV's BGR order
+(cv::imread IMREAD_UNCHANGED, CvUtil.cpp:23-29).
+"""
+import struct
+import zlib
+
+import numpy as np
+
+
+def write_pfm(path, m):
+    m = np.ascontiguousarray(m, dtype="<f4")
+    h, w = m.shape
+    with open(path, "wb") as f:
+        f.write(b"Pf\n")
+        f.write(("%d %d\n" % (w, h)).encode())
+        f.write(b"-1.0\n")
+        f.write(m.tobytes())
+
+
+def read_pfm(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    nl1 = data.index(b"\n")
+    if data[:nl1] != b"Pf":
+        raise ValueError("expected 'Pf' in 1-channel .pfm file header: %s" % path)
+    nl2 = data.index(b"\n", nl1 + 1)
+    w, h = map(int, data[nl1 + 1:nl2].split())
+    nl3 = data.index(b"\n", nl2 + 1)
+    if float(data[nl2 + 1:nl3]) > 0:
+        raise ValueError("only little endian .pfm files supported: %s" % path)
+    return np.frombuffer(data, dtype="<f4", count=w * h, offset=nl3 + 1).reshape(h, w).copy()
+
+
+def _chunk(tag, payload):
+    return struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
+
+
+def _write_png(path, arr, bitdepth):
+    arr = np.asarray(arr)
+    if arr.ndim == 2:
+        arr = arr[..., None]
+    h, w, ch = arr.shape
+    color_type = {1: 0, 3: 2, 4: 6}[ch]
+    if ch >= 3:  # BGR(A) -> RGB(A)
+        arr = arr[..., [2, 1, 0] + ([3] if ch == 4 else [])]
+    dt = ">u2" if bitdepth == 16 else "u1"
+    raw = np.ascontiguousarray(arr.astype(dt)).reshape(h, -1).view(np.uint8)
+    rows = np.concatenate([np.zeros((h, 1), dtype=np.uint8), raw], axis=1)  # filter type 0
+    png = b"\x89PNG\r\n\x1a\n"
+    png += _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, bitdepth, color_type, 0, 0, 0))
+    png += _chunk(b"IDAT", zlib.compress(rows.tobytes(), 3))
+    png += _chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(png)
+
+
+def write_png16(path, arr):
+    _write_png(path, arr, 16)
+
+
+def write_png8(path, arr):
+    _write_png(path, arr, 8)
+
+
+def read_png(path):
+    """-> uint8 / uint16 array [h, w] or [h, w, 3|4] in BGR(A) order."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("not a PNG: %s" % path)
+    pos, idat, ihdr = 8, [], None
+    while pos < len(data):
+        (n,) = struct.unpack(">I", data[pos:pos + 4])
+        tag = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if tag == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+    w, h, bitdepth, color_type, _, _, interlace = ihdr
+    if interlace or bitdepth not in (8, 16) or color_type not in (0, 2, 6):
+        raise ValueError("unsupported PNG flavour: %s" % path)
+    ch = {0: 1, 2: 3, 6: 4}[color_type]
+    bpp = ch * bitdepth // 8
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp)
+    out = np.zeros((h, w * bpp), dtype=np.uint8)
+    prev = np.zeros(w * bpp, dtype=np.int32)
+    for y in range(h):
+        ft = raw[y, 0]
+        line = raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        elif ft == 1:
+            cur = line.copy()
+            for i in range(bpp, w * bpp):
+                cur[i] = (cur[i] + cur[i - bpp]) & 255
+        elif ft == 3:
+            cur = line.copy()
+            for i in range(w * bpp):
+                left = cur[i - bpp] if i >= bpp else 0
+                cur[i] = (cur[i] + ((left + prev[i]) >> 1)) & 255
+        elif ft == 4:
+            cur = line.copy()
+            for i in range(w * bpp):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (cur[i] + pr) & 255
+        else:
+            raise ValueError("bad PNG filter")
+        out[y] = cur
+        prev = cur
+    arr = out.view(">u2").astype(np.uint16) if bitdepth == 16 else out
+    arr = arr.reshape(h, w, ch)
+    if ch >= 3:
+        arr = arr[..., [2, 1, 0] + ([3] if ch == 4 else [])]
+    return np.ascontiguousarray(arr[..., 0] if ch == 1 else arr)
+
+
+def load_color_u16(path):
+    """cv_util::loadImage<Vec3w> (CvUtil.h:196-284): depth -> 16U (x257 from 8-bit), channels -> BGR."""
+    a = read_png(path)
+    if a.dtype == np.uint8:
+        a = a.astype(np.uint16) * 257
+    if a.ndim == 2:
+        a = np.repeat(a[..., None], 3, axis=2)
+    return np.ascontiguousarray(a[..., :3])
+
+
+def load_mask(path):
+    """cv_util::loadImage<bool> (CvUtil.h:235-239): 8-bit, threshold > 127 -> 1."""
+    a = read_png(path)
+    if a.ndim == 3:
+        # COLOR_BGR2GRAY is not what masks go through in practice (they are 1-channel); take channel 0
+        a = a[..., 0]
+    if a.dtype == np.uint16:
+        a = np.rint(a.astype(np.float64) * (255.0 / 65535.0)).astype(np.uint8)
+    return (a > 127).astype(np.uint8)

@@ -1,0 +1,184 @@
+/*
+ * derp_hip.h — C-ABI of the MI355X-native depth_estimation hot path.
+ *
+ * The reference (facebook360_dep) has no plugin/FFI seam for this path: its boundary is the
+ * DerpCLI / TemporalBilateralFilter / UpsampleDisparity process CLIs and, in-process, the free
+ * functions of source/depth_estimation/Derp.h. This header is the seam a maintainer would bind
+ * those mains to (INTEGRATION.md shows the binding). Every entry point cites the reference
+ * function it replaces (paths relative to the reference tree).
+ *
+ * Conventions: POD only, plain pointers and sizes; images row-major; colour = interleaved BGR
+ * uint16 (cv::Vec3w, DerpUtil.h:19); masks uint8 {0,1}; disparity float32 with NaN = invalid.
+ * Host pointers unless a name says `_dev`. One context per GPU, one calling thread per context.
+ * Every function returns 0 on success, non-zero on error (never throws / aborts across the ABI);
+ * derp_last_error() holds the glog-style message the CLI prints before exiting 1.
+ * There is NO CPU fallback: derp_create fails when no gfx950-class HIP device is present.
+ */
+#ifndef DERP_HIP_H
+#define DERP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct derp_ctx derp_ctx;
+
+/* Camera::Type, source/util/Camera.h:43 */
+enum { DERP_FTHETA = 0, DERP_RECTILINEAR = 1, DERP_EQUISOLID = 2, DERP_ORTHOGRAPHIC = 3 };
+
+/* One camera exactly as the rig JSON holds it (Camera::Camera(const folly::dynamic&),
+ * source/util/Camera.cpp:30-75). The library performs the constructor's work itself:
+ * right-handedness check + AngleAxis re-unitarisation (Camera.cpp:77-87), distortionMax
+ * (Camera.cpp:119-154), cosFov (Camera.cpp:204-207), then Camera::normalize (Camera.cpp:225-229). */
+typedef struct {
+  int32_t type;
+  int32_t has_principal;
+  int32_t has_distortion;
+  int32_t has_fov;
+  double origin[3];
+  double forward[3];
+  double up[3];
+  double right[3];
+  double resolution[2];
+  double focal[2];
+  double principal[2];
+  double distortion[3];
+  double fov;
+  char id[64];
+} derp_camera_desc;
+
+/* DerpCLI flags that shape the computation (source/depth_estimation/DerpCLI.cpp:40-67);
+ * derp_options_default() fills the reference defaults. */
+typedef struct {
+  float min_depth_m;            /* --min_depth_m            0.5   */
+  float max_depth_m;            /* --max_depth_m            1e4   */
+  float var_noise_floor;        /* --var_noise_floor        4e-5  */
+  float var_high_thresh;        /* --var_high_thresh        1e-3  */
+  int32_t random_proposals;     /* --random_proposals       2     */
+  int32_t ping_pong_iterations; /* --ping_pong_iterations   1     */
+  int32_t mismatches_start_level; /* --mismatches_start_level -1 (only -1 supported) */
+  int32_t do_bilateral_filter;  /* --do_bilateral_filter    1     */
+  int32_t do_median_filter;     /* --do_median_filter       1     */
+  int32_t use_foreground_masks; /* --use_foreground_masks   0     */
+  int32_t partial_coverage;     /* --partial_coverage       0     */
+  int32_t rebuild_warp_tables;  /* 1 = recompute projection warps every process_level like the
+                                   reference (DerpCLI.cpp:274); 0 = cache per level across frames */
+} derp_options;
+
+void derp_options_default(derp_options* o);
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+/* rigSrc / rigDst (DerpCLI.cpp:185-192). dst cameras are matched to src by id
+ * (mapSrcToDstIndexes, DerpUtil.cpp:75-89). */
+int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_src,
+                const derp_camera_desc* dst, int n_dst);
+void derp_destroy(derp_ctx* ctx);
+const char* derp_last_error(const derp_ctx* ctx);
+int derp_set_options(derp_ctx* ctx, const derp_options* o);
+
+/* Pyramid geometry (getPyramidLevelSizes, Derp.cpp:72-99; widthFullSize/heightFullSize,
+ * DerpCLI.cpp:212-214). Allocates the HBM-resident colour / disparity pyramid. */
+int derp_set_pyramid(derp_ctx* ctx, int num_levels, const int* widths, const int* heights,
+                     int width_full, int height_full);
+
+/* ---- inputs (loadLevelImages, ImageUtil.h:79-94; DerpCLI.cpp:235-248,276-303) ------------ */
+int derp_upload_color(derp_ctx* ctx, int level, int src, const uint16_t* bgr);
+int derp_upload_foreground_mask(derp_ctx* ctx, int level, int src, const uint8_t* mask);
+int derp_upload_background_disparity(derp_ctx* ctx, int level, int dst, const float* disp);
+/* disparity of an already-finished level (resume from disk: DerpCLI.cpp:153-155,276-303) */
+int derp_upload_disparity(derp_ctx* ctx, int level, int dst, const float* disp);
+
+/* ---- the hot path ------------------------------------------------------------------------ */
+/* One (frame, level): generateFovMasks (DerpUtil.cpp:259-276) + PyramidLevel ctor's
+ * computeVariances (PyramidLevel.h:232-247) + precomputeProjections (Derp.cpp:955-976) +
+ * upsampleDisparities from level+1 when level < num_levels-1 (UpsampleDisparityLib.cpp:149-182)
+ * + processLevel (Derp.cpp:1005-1034) minus file output. */
+int derp_process_level(derp_ctx* ctx, int level);
+/* DerpCLI main's level loop for one frame (DerpCLI.cpp:220-323), level_start >= level_end. */
+int derp_process_pyramid(derp_ctx* ctx, int level_start, int level_end);
+int derp_synchronize(derp_ctx* ctx);
+
+/* ---- outputs (PyramidLevel::saveResults, PyramidLevel.h:487-529) -------------------------- */
+int derp_download_disparity(derp_ctx* ctx, int level, int dst, float* disparity);
+/* cost / confidence of the level processed last (debug images, PyramidLevel.h:418-485) */
+int derp_download_cost(derp_ctx* ctx, int dst, float* cost, float* confidence);
+
+/* ---- stage-level entry points (Derp.h:64-133), used by the parity tests ------------------ */
+int derp_level_begin(derp_ctx* ctx, int level);     /* masks, variances, warp tables, upsample hand-off */
+int derp_stage_reproject_colors(derp_ctx* ctx);     /* reprojectColors,        Derp.cpp:978-1003 */
+int derp_stage_brute_force(derp_ctx* ctx);          /* preprocessLevel,        Derp.cpp:826-842  */
+int derp_stage_random_proposals(derp_ctx* ctx);     /* randomProposals,        Derp.cpp:844-873  */
+int derp_stage_ping_pong(derp_ctx* ctx);            /* pingPongPropagation,    Derp.cpp:540-551  */
+int derp_stage_bilateral_filter(derp_ctx* ctx);     /* bilateralFilter,        Derp.cpp:875-902  */
+int derp_stage_median_filter(derp_ctx* ctx);        /* medianFilter,           Derp.cpp:904-920  */
+int derp_stage_mask_fov(derp_ctx* ctx);             /* maskFov,                Derp.cpp:940-951  */
+int derp_level_end(derp_ctx* ctx);                  /* publish the level's disparity to the pyramid */
+/* set / read the working disparity of the current level (between stages) */
+int derp_set_level_disparity(derp_ctx* ctx, int dst, const float* disp);
+int derp_get_level_disparity(derp_ctx* ctx, int dst, float* disp);
+/* computeCost (Derp.cpp:104-226) of a caller-supplied disparity map at every interior pixel */
+int derp_cost_map(derp_ctx* ctx, int dst, const float* disp, float* cost, float* confidence);
+/* tables of the current level: which = 0 projWarp (float2), 2 projColor (u16x3), 3 projColorBias
+ * (u16x3), 4 variance of src (float), 5 fov mask of dst (u8; src ignored) */
+int derp_debug_download(derp_ctx* ctx, int dst, int src, int which, void* out);
+
+/* ---- the sibling binaries' kernels ------------------------------------------------------- */
+/* upsampleDisparities for one camera (UpsampleDisparityLib.cpp:98-182). fg_mask / fg_mask_up /
+ * bg_disp_up may be NULL when use_foreground_masks == 0. `dst` selects the FOV mask camera. */
+int derp_upsample_disparity(derp_ctx* ctx, int dst, const float* disp, int w, int h,
+                            const float* bg_disp_up, const uint8_t* fg_mask,
+                            const uint8_t* fg_mask_up, int w_up, int h_up,
+                            int use_foreground_masks, float* out);
+/* generalizedJointBilateralFilter<float, Vec3w / Vec3f> (TemporalBilateralFilter.h:39-124) */
+int derp_joint_bilateral_u16(derp_ctx* ctx, const float* image, const uint16_t* guide_bgr,
+                             const uint8_t* mask, int w, int h, int radius, float sigma,
+                             float weight0, float weight1, float weight2, float* out);
+int derp_joint_bilateral_f32(derp_ctx* ctx, const float* image, const float* guide_bgr,
+                             const uint8_t* mask, int w, int h, int radius, float sigma,
+                             float weight0, float weight1, float weight2, float* out);
+/* cv_util::maskedMedianBlur (CvUtil.h:336-385); background may be NULL */
+int derp_masked_median(derp_ctx* ctx, const float* image, const float* background,
+                       const uint8_t* mask, int w, int h, int radius, float* out);
+/* temporalJointBilateralFilter (TemporalBilateralFilter.h:126-215) over n frames of one camera;
+ * masks[t] = fg & fov as filterFrame builds them (TemporalBilateralFilter.cpp:139-160). */
+int derp_temporal_filter(derp_ctx* ctx, const uint16_t* const* guides_bgr,
+                         const float* const* disparities, const uint8_t* const* masks, int n_frames,
+                         int w, int h, int frame_offset, float sigma, int space_radius,
+                         float weight0, float weight1, float weight2, float* out);
+/* same, on disparities that already live in HBM (multi-GPU path: received over RCCL) */
+int derp_temporal_filter_dev(derp_ctx* ctx, const void* const* guides_bgrx_dev,
+                             const float* const* disparities_dev, const uint8_t* const* masks_dev,
+                             int n_frames, int w, int h, int frame_offset, float sigma,
+                             int space_radius, float weight0, float weight1, float weight2,
+                             float* out_dev);
+/* device views of the resident pyramid (for the RCCL neighbour exchange; not owned by caller) */
+int derp_dev_disparity(derp_ctx* ctx, int level, int dst, float** ptr, size_t* bytes);
+int derp_dev_color(derp_ctx* ctx, int level, int src, void** ptr_bgrx_u16, size_t* bytes);
+int derp_dev_mask(derp_ctx* ctx, int level, int dst, uint8_t** ptr_fov_and_fg, size_t* bytes);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* computeCost evaluations and (evaluation, src) pairs reaching computeSSD since the last reset:
+ * the N_cost / N_pair of BASELINE.md's B_alg = 64*N_cost + 272*N_pair. */
+int derp_get_counters(derp_ctx* ctx, uint64_t* n_cost, uint64_t* n_pair, uint64_t* insufficient);
+int derp_reset_counters(derp_ctx* ctx);
+/* per-stage HIP-event timing on the context's own stream, plus per-stage computeCost counters.
+ * stage names: "fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject",
+ * "proj_bias", "brute_force", "random_proposals", "ping_pong", "bilateral", "median", "mask_fov".
+ * level = -1 aggregates all levels. ms / launches / n_cost / n_pair may be NULL. */
+int derp_profile_enable(derp_ctx* ctx, int on);
+int derp_profile_reset(derp_ctx* ctx);
+int derp_profile_query(derp_ctx* ctx, const char* stage, int level, double* ms, int* launches,
+                       uint64_t* n_cost, uint64_t* n_pair);
+int derp_device_name(derp_ctx* ctx, char* buf, int n);
+
+/* host-only self checks (no GPU needed): restated libstdc++ algorithms the device code uses */
+int derp_host_nth_element_pairs(float* pairs, int n, int nth);
+float derp_host_minstd_uniform(int seed, uint64_t draw_index, float a, float b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DERP_HIP_H */

@@ -1,0 +1,281 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same seeded
+inputs. Integer / index / mask work must be bit-exact; float disparity within 1e-4 relative
+(BASELINE.json north_star) — in practice the stages below are bit-exact except where fp64
+libm (host) and OCML (device) transcendentals differ in the last ulp."""
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def small(built):
+    from facebook360_dep_amd import synth
+
+    n, res, widths = synth.config("small")
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    frame = synth.make_frame(rig, sizes, with_masks=True)
+    return dict(rig=rig, sizes=sizes, frame=frame, res=res, n=n)
+
+
+@pytest.fixture(scope="module")
+def gpu(small):
+    from facebook360_dep_amd import derp
+
+    g = derp.Derp(small["rig"]["cameras"], partial_coverage=1)
+    g.set_pyramid(small["sizes"], small["res"], small["res"])
+    g.upload_frame({"color": small["frame"]["color"]})
+    yield g
+    g.close()
+
+
+def _float_equal(a, b):
+    """count of elements that differ bitwise, NaN == NaN"""
+    a = np.asarray(a, dtype=np.float32)
+    b = np.asarray(b, dtype=np.float32)
+    same = (a == b) | (np.isnan(a) & np.isnan(b))
+    return int((~same).sum())
+
+
+def test_level_tables(small, gpu):
+    """fov masks, variances, projection warps, reprojected colours and colour biases."""
+    level = 1
+    L = common.oracle_level(small["rig"], small["sizes"], small["frame"], level, small["res"], small["res"],
+                            partial_coverage=True)
+    L.reproject_colors()
+    gpu.level_begin(level)
+    gpu.stage("reproject_colors")
+    n = small["n"]
+    for d in range(n):
+        assert np.array_equal(gpu.debug(d, 0, "fov"), L.fov_mask(d)), "fov mask (bit-exact) dst %d" % d
+    for s in range(n):
+        assert _float_equal(gpu.debug(0, s, "variance"), L.variance(s)) == 0, "variance src %d" % s
+    total = 0
+    for d in range(n):
+        for s in range(n):
+            if s == d:
+                continue
+            w_bad = _float_equal(gpu.debug(d, s, "warp"), L.proj(d, s, "warp"))
+            c_bad = int((gpu.debug(d, s, "color") != L.proj(d, s, "color")).sum())
+            b_bad = int((gpu.debug(d, s, "bias") != L.proj(d, s, "bias")).sum())
+            total += w_bad + c_bad + b_bad
+            # fp64 atan2/sin/cos differ in the last ulp between glibc and OCML: allow a handful of
+            # float-rounding flips per table, nothing systematic
+            assert w_bad <= 4 and c_bad <= 12 and b_bad <= 40, (d, s, w_bad, c_bad, b_bad)
+    print("table elements differing from the oracle:", total)
+
+
+def test_cost_map(small, gpu):
+    """computeCost on a random disparity field: cost and confidence."""
+    level = 1
+    L = common.oracle_level(small["rig"], small["sizes"], small["frame"], level, small["res"], small["res"],
+                            partial_coverage=True)
+    L.reproject_colors()
+    gpu.level_begin(level)
+    gpu.stage("reproject_colors")
+    w, h = small["sizes"][level]
+    rng = np.random.default_rng(5)
+    disp = (1.0 / rng.uniform(0.6, 30.0, size=(h, w))).astype(np.float32)
+    for d in (0, 3):
+        rc, rf = L.cost_map(d, disp)
+        gc, gf = gpu.cost_map(d, disp)
+        inner = (slice(1, h - 1), slice(1, w - 1))
+        bad_c, rel = common.compare_disparity(gc[inner], rc[inner], 1e-6)
+        assert _float_equal(gf[inner], rf[inner]) == 0
+        exact = _float_equal(gc[inner], rc[inner])
+        print("dst", d, "cost not bit-exact:", exact, "of", gc[inner].size, "max rel", rel)
+        assert bad_c == 0, (d, bad_c, rel)
+        assert exact <= 0.001 * gc[inner].size
+
+
+def test_brute_force(small, gpu):
+    level = len(small["sizes"]) - 1
+    L = common.oracle_level(small["rig"], small["sizes"], small["frame"], level, small["res"], small["res"],
+                            partial_coverage=True)
+    L.reproject_colors()
+    L.brute_force()
+    gpu.level_begin(level)
+    gpu.stage("reproject_colors")
+    gpu.stage("brute_force")
+    gpu.synchronize()
+    for d in range(small["n"]):
+        rd, rc, rf = L.get_dst(d)
+        gd = gpu.get_level_disparity(d)
+        gc, gf = gpu.download_cost(level, d)
+        bad, rel = common.compare_disparity(gd, rd, TOL)
+        assert bad == 0, ("disparity", d, bad, rel)
+        assert common.compare_disparity(gc, rc, 1e-5)[0] == 0
+        assert _float_equal(gf, rf) == 0
+    oc = L.counters()
+    gcnt = gpu.profile_query("brute_force", level)
+    assert gcnt["n_cost"] == oc["n_cost"], (gcnt, oc)
+    assert abs(gcnt["n_pair"] - oc["n_pair"]) <= 4, (gcnt, oc)
+
+
+def test_random_proposals_and_ping_pong(small, gpu):
+    level = 0
+    rng = np.random.default_rng(11)
+    w, h = small["sizes"][level]
+    # smooth-ish start: truth perturbed, as an upsampled coarse estimate would be
+    start = [(small["frame"]["truth"][d] * rng.uniform(0.8, 1.25, size=(h, w))).astype(np.float32)
+             for d in range(small["n"])]
+    L = common.oracle_level(small["rig"], small["sizes"], small["frame"], level, small["res"], small["res"],
+                            partial_coverage=True)
+    L.reproject_colors()
+    gpu.level_begin(level)
+    gpu.stage("reproject_colors")
+    for d in range(small["n"]):
+        L.set_dst(d, disparity=start[d])
+        gpu.set_level_disparity(d, start[d])
+    L.random_proposals()
+    gpu.stage("random_proposals")
+    changed = 0
+    for d in range(small["n"]):
+        rd, rc, rf = L.get_dst(d)
+        gd = gpu.get_level_disparity(d)
+        gc, gf = gpu.download_cost(level, d)
+        assert _float_equal(gd, rd) == 0, ("random proposals disparity", d, _float_equal(gd, rd))
+        assert common.compare_disparity(gc, rc, 1e-5)[0] == 0
+        changed += int((rd != start[d]).sum())
+    assert changed > 0, "random proposals changed nothing: the test would be vacuous"
+    L.ping_pong()
+    gpu.stage("ping_pong")
+    for d in range(small["n"]):
+        rd, rc, rf = L.get_dst(d)
+        gd = gpu.get_level_disparity(d)
+        gc, _ = gpu.download_cost(level, d)
+        assert _float_equal(gd, rd) == 0, ("ping pong disparity", d, _float_equal(gd, rd))
+        assert common.compare_disparity(gc, rc, 1e-5)[0] == 0
+    oc = L.counters()
+    rp = gpu.profile_query("random_proposals", level)
+    pp = gpu.profile_query("ping_pong", level)
+    assert rp["n_cost"] + pp["n_cost"] == oc["n_cost"]
+
+
+def test_filters(small, gpu):
+    from oracle import oracle_lib as O
+
+    rng = np.random.default_rng(3)
+    w, h = small["sizes"][0]
+    guide = small["frame"]["color"][0][2]
+    disp = (1.0 / rng.uniform(0.6, 30.0, size=(h, w))).astype(np.float32)
+    disp[rng.random((h, w)) < 0.02] = np.nan
+    mask = (rng.random((h, w)) > 0.1).astype(np.uint8)
+    clean = np.nan_to_num(disp, nan=0.3)
+    for radius in (1, 3, 5):
+        ref = O.joint_bilateral_u16(clean, guide, mask, radius, 0.005, 0.5, 1.0, 1.0)
+        got = gpu.joint_bilateral_u16(clean, guide, mask, radius, 0.005, 0.5, 1.0, 1.0)
+        bad, rel = common.compare_disparity(got, ref, 1e-5)
+        print("bilateral r=%d max rel %.3g bit-diff %d" % (radius, rel, _float_equal(got, ref)))
+        assert bad == 0, (radius, bad, rel)
+    gf = (guide.astype(np.float32) / 65535.0)
+    ref = O.joint_bilateral_f32(clean, gf, mask, 5, 0.05, 0.5, 0.5, 1.0)
+    got = gpu.joint_bilateral_f32(clean, gf, mask, 5, 0.05, 0.5, 0.5, 1.0)
+    assert common.compare_disparity(got, ref, 1e-5)[0] == 0
+    bg = rng.random((h, w)).astype(np.float32)
+    for background in (None, bg):
+        ref = O.masked_median(disp, background, mask, 1)
+        got = gpu.masked_median(disp, background, mask, 1)
+        assert _float_equal(got, ref) == 0
+
+
+def test_upsample(small, gpu):
+    from oracle import oracle_lib as O
+
+    rs, rd, _ = common.oracle_rigs(small["rig"])
+    rng = np.random.default_rng(9)
+    for (sw, sh), (dw, dh) in (((50, 50), (60, 60)), ((60, 60), (80, 80)), ((64, 64), (128, 128)), ((40, 30), (100, 76))):
+        disp = (1.0 / rng.uniform(0.6, 30.0, size=(sh, sw))).astype(np.float32)
+        disp[rng.random((sh, sw)) < 0.05] = np.nan
+        ref = O.upsample_disparity(rd, 1, disp, dw, dh)
+        got = gpu.upsample_disparity(1, disp, dw, dh)
+        assert _float_equal(got, ref) == 0, ((sw, sh), (dw, dh), _float_equal(got, ref))
+        fg = (rng.random((sh, sw)) > 0.4).astype(np.uint8)
+        fg_up = (rng.random((dh, dw)) > 0.3).astype(np.uint8)
+        bg_up = rng.random((dh, dw)).astype(np.float32)
+        ref = O.upsample_disparity(rd, 1, disp, dw, dh, bg_up, fg, fg_up)
+        got = gpu.upsample_disparity(1, disp, dw, dh, bg_up, fg, fg_up)
+        assert _float_equal(got, ref) == 0, ("masked", (sw, sh), (dw, dh))
+
+
+def test_temporal_filter(small, gpu):
+    from oracle import oracle_lib as O
+
+    rng = np.random.default_rng(21)
+    w, h = small["sizes"][0]
+    n = 5
+    base = small["frame"]["color"][0][1].astype(np.int64)
+    guides = [np.clip(base + rng.integers(-300, 300, size=base.shape), 0, 65535).astype(np.uint16) for _ in range(n)]
+    disps = [(1.0 / rng.uniform(0.6, 30.0, size=(h, w))).astype(np.float32) for _ in range(n)]
+    masks = [(rng.random((h, w)) > 0.05).astype(np.uint8) for _ in range(n)]
+    for off, cnt in ((2, 5), (0, 3), (1, 2)):
+        ref = O.temporal_filter(guides[:cnt], disps[:cnt], masks[:cnt], off, 0.01, 1, 0.5, 1.0, 0.5)
+        got = gpu.temporal_filter(guides[:cnt], disps[:cnt], masks[:cnt], off, 0.01, 1, 0.5, 1.0, 0.5)
+        bad, rel = common.compare_disparity(got, ref, 1e-5)
+        assert bad == 0, (off, cnt, bad, rel)
+
+
+def _run_pyramid(small, **opts):
+    from facebook360_dep_amd import derp
+
+    ref = common.oracle_pyramid(small["rig"], small["sizes"], small["frame"], small["res"], small["res"], **opts)
+    gopts = {k: int(v) if isinstance(v, bool) else v for k, v in opts.items() if k != "threads"}
+    g = derp.Derp(small["rig"]["cameras"], **gopts)
+    g.set_pyramid(small["sizes"], small["res"], small["res"])
+    g.upload_frame(small["frame"] if opts.get("use_foreground_masks") else {"color": small["frame"]["color"]})
+    g.process_pyramid()
+    g.synchronize()
+    stats = {}
+    for level in sorted(ref):
+        nbad = npx = 0
+        worst = 0.0
+        for d in range(small["n"]):
+            got = g.download_disparity(level, d)
+            bad, rel = common.compare_disparity(got, ref[level][d], TOL)
+            nbad += bad
+            npx += got.size
+            worst = max(worst, rel)
+        stats[level] = (nbad, npx, worst)
+    g.close()
+    return stats
+
+
+def test_full_pyramid(small):
+    """processLevel over the whole pyramid (brute force, proposals, ping-pong, bilateral, median,
+    maskFov, Lanczos hand-off): disparity within 1e-4 relative of the oracle."""
+    stats = _run_pyramid(small, partial_coverage=True)
+    print("full pyramid (level: bad, pixels, max rel):", stats)
+    for level, (bad, npx, worst) in stats.items():
+        assert bad <= 1e-4 * npx, (level, bad, npx, worst)
+
+
+def test_full_pyramid_foreground_masks(small):
+    """BASELINE config 5's mask path: foreground masks + background disparity through every stage."""
+    stats = _run_pyramid(small, partial_coverage=True, use_foreground_masks=True)
+    print("fg-mask pyramid (level: bad, pixels, max rel):", stats)
+    for level, (bad, npx, worst) in stats.items():
+        assert bad <= 1e-4 * npx, (level, bad, npx, worst)
+
+
+def test_destination_subset(small):
+    """--cameras=cam4,cam1: destinations filtered and reordered (ImageUtil.cpp:110-125)."""
+    from facebook360_dep_amd import derp
+
+    ids = ["cam4", "cam1"]
+    ref = common.oracle_pyramid(small["rig"], small["sizes"], small["frame"], small["res"], small["res"],
+                                dst_ids=ids, partial_coverage=True)
+    cams = small["rig"]["cameras"]
+    g = derp.Derp(cams, derp.filter_destinations(cams, ",".join(ids)), partial_coverage=1)
+    g.set_pyramid(small["sizes"], small["res"], small["res"])
+    g.upload_frame({"color": small["frame"]["color"]})
+    g.process_pyramid()
+    g.synchronize()
+    for d in range(2):
+        bad, rel = common.compare_disparity(g.download_disparity(0, d), ref[0][d], TOL)
+        assert bad <= 2, (d, bad, rel)
+    g.close()
