@@ -1,0 +1,279 @@
+#!/usr/bin/env python
+"""bench.py — depth Mpix/s per GPU, full pyramid (BASELINE.json metric).
+
+A step = one coarse-to-fine pass of the depth path over one synthetic frame whose colour pyramid
+is already resident in HBM: projection tables, colour reprojection, brute force, random proposals,
+ping-pong, bilateral, median, FOV mask and the between-level upsample, for every destination camera
+and every pyramid level. N = 1 runs BASELINE config 2 (16 cameras, 2048^2, single frame); N > 1
+runs config 3's shape: frame r on GPU r (weak scaling), with the per-level temporal joint-bilateral
+filter whose +-2-frame disparity window is exchanged over RCCL (all_gather on xGMI).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement), extended with
+`roofline` (dominant kernel = level-0 ping-pong) and `cpu_baseline` (the CPU oracle timed on a
+bounded sample on rank 0 at N = 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", help="cfg1 | cfg2 | cfg4 | small | tiny (default: BASELINE config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="auto")
+    ap.add_argument("--temporal", type=int, default=-1, help="-1: on iff gpus > 1")
+    ap.add_argument("--cache-warp-tables", type=int, default=0,
+                    help="1 = keep the rig-only projection warps across steps (default 0: rebuilt every step, as the "
+                         "reference does per frame)")
+    return ap.parse_args()
+
+
+def b_alg(n_cost, n_pair):
+    """logical gather bytes of the cost loop."""
+    return 64.0 * n_cost + 272.0 * n_pair
+
+
+def cpu_baseline(cams_n, widths_from, sample):
+    """The CPU oracle ("port") on a bounded sample of the same workload: the same rig, the pyramid
+    truncated to start at `sample` px wide. Returns (Mpix/s of that sample, cores, description)."""
+    import numpy as np  # noqa: F401
+
+    from facebook360_dep_amd import synth
+    from tests import common
+
+    rig = synth.make_rig(cams_n, sample)
+    widths = [w for w in widths_from if w <= sample]
+    sizes = synth.level_sizes(sample, sample, widths)
+    frame = synth.make_frame(rig, sizes)
+    cores = os.cpu_count() or 1
+    t0 = time.time()
+    cnt = {}
+    common.oracle_pyramid(rig, sizes, frame, sample, sample, counters=cnt, partial_coverage=True, threads=-1)
+    dt = time.time() - t0
+    mpix = cams_n * sample * sample / dt / 1e6
+    return mpix, cores, "%d-camera %dx%d rig, full %d-level pyramid, %.1f s on %d threads" % (
+        cams_n, sample, sample, len(sizes), dt, cores), cnt
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+
+    from facebook360_dep_amd import derp, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    dist = None
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    temporal = (world > 1) if args.temporal < 0 else bool(args.temporal)
+
+    n_cams, res, widths = synth.config(args.config)
+    rig = synth.make_rig(n_cams, res)
+    sizes = synth.level_sizes(res, res, widths)
+    frame_index = rank  # frame t -> GPU t (one frame per GPU)
+    frame = synth.make_frame(rig, sizes, frame=frame_index, seed=360 + frame_index, device="cuda")
+
+    g = derp.Derp(rig["cameras"], device=local_rank, partial_coverage=int(n_cams <= 4),
+                  rebuild_warp_tables=int(not args.cache_warp_tables))
+    g.set_pyramid(sizes, res, res)
+    t0 = time.time()
+    g.upload_frame(frame)
+    upload_s = time.time() - t0
+    upload_bytes = sum(w * h for (w, h) in sizes) * n_cams * 6
+    n_levels = len(sizes)
+
+    # ---- temporal stage (config 3): per level, all ranks exchange their raw level disparity and
+    # colour guide, then each filters its own frame over the window [t-2, t+2] clamped to the
+    # sequence (populateMinMaxFrame, TemporalBilateralFilter.cpp:96-119).
+    tbuf = {}
+
+    def wrap(ptr, nbytes, dtype, shape):
+        class _A:
+            pass
+
+        a = _A()
+        a.__cuda_array_interface__ = {"shape": shape, "typestr": np.dtype(dtype).str, "data": (ptr, False),
+                                      "version": 3}
+        return torch.as_tensor(a, device=torch.device("cuda", local_rank))
+
+    def temporal_level(level):
+        w, h = sizes[level]
+        n = w * h
+        D = n_cams
+        # local views of the resident pyramid
+        p, nb = g.dev_disparity(level, 0)
+        disp = wrap(p, nb * D, np.float32, (D, h, w))
+        p, nb = g.dev_color(level, 0)
+        col = wrap(p, nb * D, np.uint16, (D, h, w, 4))
+        p, nb = g.dev_mask(level, 0)
+        msk = wrap(p, nb * D, np.uint8, (D, h, w))
+        key = level
+        if key not in tbuf:
+            tbuf[key] = (torch.empty((world, D, h, w), dtype=torch.float32, device=disp.device),
+                         torch.empty((world, D, h, w, 4), dtype=torch.uint16, device=disp.device),
+                         torch.empty((world, D, h, w), dtype=torch.uint8, device=disp.device),
+                         torch.empty((D, h, w), dtype=torch.float32, device=disp.device))
+        all_disp, all_col, all_msk, out = tbuf[key]
+        g.synchronize()
+        if world > 1:
+            dist.all_gather_into_tensor(all_disp, disp.contiguous())
+            dist.all_gather_into_tensor(all_col.view(torch.int16), col.view(torch.int16).contiguous())
+            dist.all_gather_into_tensor(all_msk, msk.contiguous())
+        else:
+            all_disp[0].copy_(disp)
+            all_col[0].copy_(col)
+            all_msk[0].copy_(msk)
+        torch.cuda.synchronize()
+        lo, hi = max(0, rank - 2), min(world - 1, rank + 2)
+        radius = 1  # max(ceil(1 * 0.9^level), 1), TemporalBilateralFilter.cpp:165-168
+        for d in range(D):
+            gp = [all_col[t, d].data_ptr() for t in range(lo, hi + 1)]
+            ip = [all_disp[t, d].data_ptr() for t in range(lo, hi + 1)]
+            mp = [all_msk[t, d].data_ptr() for t in range(lo, hi + 1)]
+            # sigma 0.01; weights (b, g, b) = (0.5, 1.0, 0.5) — TemporalBilateralFilter.cpp:55,176-178
+            g.temporal_filter_dev(gp, ip, mp, w, h, rank - lo, 0.01, radius, 0.5, 1.0, 0.5, out[d].data_ptr())
+        g.synchronize()
+        disp.copy_(out)  # "Transfer": filtered level overwrites disparity_levels/level_L (pipeline.py:397-408)
+        torch.cuda.synchronize()
+
+    def step():
+        if temporal:
+            for level in range(n_levels - 1, -1, -1):
+                g.process_level(level)
+                temporal_level(level)
+        else:
+            g.process_pyramid()
+
+    def fence():
+        g.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    g.profile_reset()
+    g.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    g.profile_enable(False)
+
+    w0, h0 = sizes[0]
+    total_mpix = world * args.steps * n_cams * w0 * h0 / 1e6
+    value = total_mpix / dt
+
+    # ---- roofline of the dominant kernel: level-0 ping-pong (one launch per step)
+    pp = g.profile_query("ping_pong", 0)
+    launches = max(pp["launches"], 1)
+    kernel_ms = pp["ms"] / launches
+    alg_bytes = b_alg(pp["n_cost"], pp["n_pair"]) / launches
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj.get(args.config, {}).get("ping_pong_level0_bytes_per_launch")
+        except Exception:
+            traffic = None
+    stage_ms = {s: round(g.profile_query(s)["ms"] / args.steps, 3) for s in derp.STAGES}
+    cnt = g.counters()
+    whole_alg = b_alg(cnt["n_cost"], cnt["n_pair"]) / args.steps
+
+    out = {
+        "metric": "depth Mpix/s per GPU (full pyramid, 16-cam 2048^2 rig); % HBM-read roofline",
+        "value": round(value, 3),
+        "unit": "Mpix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 photometry + f64 geometry over u16 texels",
+        "data": "synthetic",
+        "config": {
+            "workload": ("BASELINE config 2: %d-camera %dx%d synthetic rig, single frame, full %d-level pyramid"
+                         % (n_cams, res, res, n_levels)) if not temporal else
+                        ("BASELINE config 3 shape: %d-camera %dx%d rig, %d-frame sequence one frame per GPU, "
+                         "per-level temporal filter with RCCL all_gather of the level disparity" %
+                         (n_cams, res, res, world)),
+            "name": args.config,
+            "cameras": n_cams,
+            "resolution": [res, res],
+            "levels": [list(s) for s in sizes],
+            "frames_per_step": world,
+            "temporal_filter": temporal,
+            "warp_tables": "cached" if args.cache_warp_tables else "rebuilt every step",
+            "parallelism": "frames x%d" % world,
+        },
+        "per_gpu_value": round(value / world, 3),
+        "roofline": {
+            "kernel": "k_ping_pong @ level 0",
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic,
+            "kernel_ms": round(kernel_ms, 3),
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "n_cost_per_launch": pp["n_cost"] / launches,
+            "n_pair_per_launch": pp["n_pair"] / launches,
+            "whole_step_algorithmic_GBps": round(whole_alg / (dt / args.steps) / 1e9, 1),
+            "whole_step_frac_of_peak": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+        },
+        "stage_ms_per_step": stage_ms,
+        "input_upload": {"bytes": upload_bytes, "seconds": round(upload_s, 3),
+                         "note": "host->HBM staging of the colour pyramid, outside the timed region"},
+        "device": g.device_name(),
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sample = {"cfg2": 256, "cfg4": 256, "cfg1": 256}.get(args.config, min(res, 128))
+        if args.cpu_sample != "auto":
+            sample = int(args.cpu_sample)
+        mpix, cores, desc, _ = cpu_baseline(n_cams, widths, sample)
+        out["cpu_baseline"] = {"value": round(mpix, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+                               "sample": desc}
+    g.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

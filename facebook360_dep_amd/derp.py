@@ -59,6 +59,13 @@ def lib():
                 "libderp_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the depth path."
             )
+        # One HIP runtime per process: PyTorch-ROCm preloads its bundled libamdhip64 by path, and a
+        # second copy (the system one this library would otherwise pull in) cannot open the device.
+        # Importing torch first makes libderp_hip.so bind to the runtime torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.derp_last_error.restype = C.c_char_p
         _lib.derp_last_error.argtypes = [C.c_void_p]

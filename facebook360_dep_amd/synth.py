@@ -5,7 +5,7 @@ Writes / returns data in the reference's layout: rig JSON as `Camera::loadRig` r
 (`video/color_levels/level_N/<cam>/<frame>.png`, source/util/ImageTypes.h:23), level sizes
 from scripts/render/config.py:46 + resize.py:71-74.
 
-numpy only; independent of both the HIP path and the oracle.
+numpy + torch (rendering only); independent of both the HIP path and the oracle.
 """
 import json
 import math
@@ -79,13 +79,18 @@ def make_rig(n_cams, res, radius=0.25, layout=None, fov=math.pi / 2):
 
 
 # ---------------------------------------------------------------- camera (generator's own)
-def _distort(r, d):
-    r2 = r * r
-    return r * (1 + r2 * (d[0] + r2 * (d[1] + r2 * d[2])))
+# Rendering runs on torch tensors (CPU threads here, the GPU when one is present): plumbing only —
+# the generated images are *inputs* to both the HIP path and the oracle.
+def _device(device=None):
+    import torch
+
+    if device is not None:
+        return torch.device(device)
+    return torch.device("cuda" if torch.cuda.is_available() else "cpu")
 
 
 def _undistort(y, d, iters=12):
-    x = y.copy()
+    x = y.clone()
     for _ in range(iters):
         x2 = x * x
         f = x * (1 + x2 * (d[0] + x2 * (d[1] + x2 * d[2]))) - y
@@ -94,49 +99,51 @@ def _undistort(y, d, iters=12):
     return x
 
 
-def pixel_rays(cam, w, h):
+def pixel_rays(cam, w, h, device=None):
     """Unit ray directions (rig space) for the pixel centres of a w x h image of `cam`."""
+    import torch
+
+    dev = _device(device)
     res = cam["resolution"]
     fx, fy = cam["focal"][0] * w / res[0], cam["focal"][1] * h / res[1]
     px, py = cam["principal"][0] * w / res[0], cam["principal"][1] * h / res[1]
-    xs = (np.arange(w, dtype=np.float64) + 0.5 - px) / fx
-    ys = (np.arange(h, dtype=np.float64) + 0.5 - py) / fy
-    sx, sy = np.meshgrid(xs, ys)
-    norm = np.sqrt(sx * sx + sy * sy)
+    xs = (torch.arange(w, dtype=torch.float64, device=dev) + 0.5 - px) / fx
+    ys = (torch.arange(h, dtype=torch.float64, device=dev) + 0.5 - py) / fy
+    sy, sx = torch.meshgrid(ys, xs, indexing="ij")
+    norm = torch.sqrt(sx * sx + sy * sy)
     theta = _undistort(norm, cam.get("distortion", (0, 0, 0)))
-    s = np.where(norm > 0, np.sin(theta) / np.maximum(norm, 1e-300), 0.0)
-    cx, cy, cz = s * sx, s * sy, -np.cos(theta)
-    R = np.array([cam["right"], cam["up"], (-np.asarray(cam["forward"])).tolist()])
-    d = np.stack([cx, cy, cz], -1) @ R  # R^T * unit
-    return d, theta
+    s = torch.where(norm > 0, torch.sin(theta) / norm.clamp_min(1e-300), torch.zeros_like(norm))
+    unit = torch.stack([s * sx, s * sy, -torch.cos(theta)], -1)
+    R = torch.tensor([cam["right"], cam["up"], [-v for v in cam["forward"]]], dtype=torch.float64, device=dev)
+    return unit @ R  # R^T * unit
 
 
 # ---------------------------------------------------------------- scene
 PLANES = [  # (unit normal n, offset c: n.x = c, centre, half-size) — three inset planes 1.5–3 m
-    (np.array([1.0, 0.0, 0.0]), 1.5, np.array([1.5, 0.2, 0.1]), 0.9),
-    (np.array([-0.6, 0.8, 0.0]), 2.2, np.array([-1.32, 1.76, -0.2]), 1.3),
-    (np.array([0.0, -0.6, -0.8]), 3.0, np.array([0.3, -1.8, -2.4]), 1.8),
+    ((1.0, 0.0, 0.0), 1.5, (1.5, 0.2, 0.1), 0.9),
+    ((-0.6, 0.8, 0.0), 2.2, (-1.32, 1.76, -0.2), 1.3),
+    ((0.0, -0.6, -0.8), 3.0, (0.3, -1.8, -2.4), 1.8),
 ]
 SPHERE_R = 4.0
 
 
 def _hash3(ix, iy, iz, seed):
-    h = (ix.astype(np.uint32) * np.uint32(73856093)) ^ (iy.astype(np.uint32) * np.uint32(19349663)) ^ (
-        iz.astype(np.uint32) * np.uint32(83492791)
-    )
-    h ^= np.uint32(seed)
-    h = (h ^ (h >> np.uint32(13))) * np.uint32(1274126177)
-    h ^= h >> np.uint32(16)
-    return (h & np.uint32(0xFFFFFF)).astype(np.float32) * np.float32(1.0 / 0xFFFFFF)
+    m = 0xFFFFFFFF
+    h = ((ix * 73856093) & m) ^ ((iy * 19349663) & m) ^ ((iz * 83492791) & m) ^ (seed & m)
+    h = ((h ^ (h >> 13)) * 1274126177) & m
+    h = h ^ (h >> 16)
+    return (h & 0xFFFFFF).to(dtype=__import__("torch").float32) * (1.0 / 0xFFFFFF)
 
 
 def value_noise(p, freq, seed):
-    q = (p * freq).astype(np.float32)
-    i0 = np.floor(q)
+    import torch
+
+    q = (p * freq).to(torch.float32)
+    i0 = torch.floor(q)
     f = q - i0
     f = f * f * (3 - 2 * f)
-    i0 = i0.astype(np.int64) & 0xFFFFF
-    out = np.zeros(p.shape[:-1], dtype=np.float32)
+    i0 = i0.to(torch.int64) & 0xFFFFF
+    out = torch.zeros(p.shape[:-1], dtype=torch.float32, device=p.device)
     for dz in (0, 1):
         wz = f[..., 2] if dz else 1 - f[..., 2]
         for dy in (0, 1):
@@ -149,49 +156,60 @@ def value_noise(p, freq, seed):
 
 def texture(p, seed=360):
     """4-octave value noise hashed from world position -> 3 channels in [0.08, 0.92]."""
+    import torch
+
+    octs = [value_noise(p, 6.0 * (2.1**o), seed * 31 + o) for o in range(5)]
     chans = []
     for c in range(3):
-        v = np.zeros(p.shape[:-1], dtype=np.float32)
+        v = torch.zeros_like(octs[0])
         amp, tot = 1.0, 0.0
         for o in range(4):
-            v += amp * value_noise(p, 6.0 * (2.1**o), seed * 31 + c * 7 + o)
+            # each channel mixes a different rotation of the octave stack, so channels decorrelate
+            v += amp * octs[(o + c) % 5] if o else amp * octs[c]
             tot += amp
             amp *= 0.6
         chans.append(0.08 + 0.84 * v / tot)
-    return np.stack(chans, -1)
+    return torch.stack(chans, -1)
 
 
 def intersect(origin, d, shift):
     """Nearest hit of rays origin + t d with the scene translated by `shift`.
-    Returns (t, hit point in scene coordinates, is_plane)."""
-    o = origin - shift
+    Returns (t, hit point in scene coordinates, is_plane, t of the background sphere alone)."""
+    import torch
+
+    o = torch.tensor([origin[i] - shift[i] for i in range(3)], dtype=torch.float64, device=d.device)
     b = d @ o
     c = float(o @ o) - SPHERE_R**2
-    t = -b + np.sqrt(np.maximum(b * b - c, 0.0))
-    is_plane = np.zeros(t.shape, dtype=bool)
+    tb = -b + torch.sqrt((b * b - c).clamp_min(0.0))
+    t = tb.clone()
+    is_plane = torch.zeros(t.shape, dtype=torch.bool, device=d.device)
     for n, cc, centre, half in PLANES:
+        n = torch.tensor(n, dtype=torch.float64, device=d.device)
+        centre = torch.tensor(centre, dtype=torch.float64, device=d.device)
         denom = d @ n
-        tp = (cc - float(o @ n)) / np.where(np.abs(denom) > 1e-9, denom, 1e-9)
+        denom = torch.where(denom.abs() > 1e-9, denom, torch.full_like(denom, 1e-9))
+        tp = (cc - float(o @ n)) / denom
         hit = o + tp[..., None] * d
-        inside = (tp > 0) & (np.max(np.abs(hit - centre), axis=-1) < half) & (tp < t)
-        t = np.where(inside, tp, t)
+        inside = (tp > 0) & ((hit - centre).abs().amax(dim=-1) < half) & (tp < t)
+        t = torch.where(inside, tp, t)
         is_plane |= inside
-    return t, o + t[..., None] * d, is_plane
+    return t, o + t[..., None] * d, is_plane, tb
 
 
-def render_camera(cam, w, h, frame=0, seed=360):
+def render_camera(cam, w, h, frame=0, seed=360, device=None, as_numpy=True):
     """-> (bgr u16 [h,w,3], true disparity f32 [h,w], plane mask u8 [h,w], background disparity f32)."""
-    d, _ = pixel_rays(cam, w, h)
-    shift = np.array([0.02 * frame, 0.0, 0.0])  # scene translated 2 cm / frame
-    origin = np.asarray(cam["origin"], dtype=np.float64)
-    t, p, is_plane = intersect(origin, d, shift)
-    rgb = texture(p.astype(np.float32), seed)
-    bgr = np.clip(np.rint(rgb[..., ::-1] * 65535.0), 0, 65535).astype(np.uint16)
-    # background-only (sphere) disparity for the foreground-mask path
-    o = origin - shift
-    b = d @ o
-    tb = -b + np.sqrt(np.maximum(b * b - (float(o @ o) - SPHERE_R**2), 0.0))
-    return bgr, (1.0 / t).astype(np.float32), is_plane.astype(np.uint8), (1.0 / tb).astype(np.float32)
+    import torch
+
+    d = pixel_rays(cam, w, h, device)
+    shift = (0.02 * frame, 0.0, 0.0)  # scene translated 2 cm / frame
+    t, p, is_plane, tb = intersect(cam["origin"], d, shift)
+    rgb = texture(p.to(torch.float32), seed)
+    bgr = torch.clamp(torch.round(rgb.flip(-1) * 65535.0), 0, 65535).to(torch.int32)
+    out = (bgr, (1.0 / t).to(torch.float32), is_plane.to(torch.uint8), (1.0 / tb).to(torch.float32))
+    if as_numpy:
+        return (out[0].cpu().numpy().astype(np.uint16), out[1].cpu().numpy(), out[2].cpu().numpy(),
+                out[3].cpu().numpy())
+    return out
 
 
 # ---------------------------------------------------------------- pyramid (area average)
@@ -208,26 +226,38 @@ def _area_matrix(ssize, dsize):
 
 
 def resize_area(img, dw, dh):
-    """Area-average downsample (cv2.INTER_AREA semantics up to rounding), any channel count."""
-    h, w = img.shape[:2]
+    """Area-average downsample (cv2.INTER_AREA semantics up to rounding); numpy or torch in,
+    same kind out; any channel count."""
+    import torch
+
+    is_np = isinstance(img, np.ndarray)
+    x = torch.from_numpy(np.ascontiguousarray(img)) if is_np else img
+    h, w = x.shape[:2]
     if (w, h) == (dw, dh):
-        return img.copy()
-    my, mx = _area_matrix(h, dh), _area_matrix(w, dw)
-    x = img.astype(np.float64)
+        return img.copy() if is_np else img.clone()
+    my = torch.from_numpy(_area_matrix(h, dh)).to(x.device)
+    mx = torch.from_numpy(_area_matrix(w, dw)).to(x.device)
+    x = x.to(torch.float64)
     if x.ndim == 2:
-        return my @ x @ mx.T
-    return np.einsum("yh,hwc,xw->yxc", my, x, mx, optimize=True)
+        r = my @ x @ mx.T
+    else:
+        r = torch.einsum("yh,hwc,xw->yxc", my, x, mx)
+    return r.cpu().numpy() if is_np else r
 
 
 def build_pyramid(bgr, sizes):
+    import torch
+
+    is_np = isinstance(bgr, np.ndarray)
+    x = torch.from_numpy(bgr.astype(np.int32)) if is_np else bgr
     out = []
     for (w, h) in sizes:
-        r = resize_area(bgr, w, h)
-        out.append(np.clip(np.rint(r), 0, 65535).astype(np.uint16))
+        r = torch.clamp(torch.round(resize_area(x, w, h).to(torch.float64)), 0, 65535)
+        out.append(r.cpu().numpy().astype(np.uint16))
     return out
 
 
-def make_frame(rig, sizes, frame=0, seed=360, with_masks=False):
+def make_frame(rig, sizes, frame=0, seed=360, with_masks=False, device=None):
     """Render every camera of `rig` and build its pyramid.
     -> dict(color[level][cam] u16, truth[cam] f32 at level 0, masks[level][cam], bg_disp[level][cam])"""
     cams = rig["cameras"]
@@ -237,15 +267,15 @@ def make_frame(rig, sizes, frame=0, seed=360, with_masks=False):
     bgd = [[None] * len(cams) for _ in sizes]
     truth = []
     for ci, cam in enumerate(cams):
-        bgr, disp, is_plane, bg = render_camera(cam, w0, h0, frame, seed)
-        truth.append(disp)
+        bgr, disp, is_plane, bg = render_camera(cam, w0, h0, frame, seed, device, as_numpy=False)
+        truth.append(disp.cpu().numpy())
         for li, im in enumerate(build_pyramid(bgr, sizes)):
             color[li][ci] = im
         if with_masks:
             for li, (w, h) in enumerate(sizes):
-                m = resize_area(is_plane.astype(np.float64) * 255.0, w, h)
-                masks[li][ci] = (m > 127).astype(np.uint8)  # resize.py threshold=127, CvUtil.h:235-239
-                bgd[li][ci] = resize_area(bg, w, h).astype(np.float32)
+                m = resize_area(is_plane.to(bgr.dtype) * 255, w, h)
+                masks[li][ci] = (m > 127).cpu().numpy().astype(np.uint8)  # resize.py threshold, CvUtil.h:235-239
+                bgd[li][ci] = resize_area(bg, w, h).cpu().numpy().astype(np.float32)
     return {"color": color, "truth": truth, "masks": masks if with_masks else None,
             "bg_disp": bgd if with_masks else None, "sizes": sizes}
 
