@@ -71,7 +71,7 @@ def main():
     import numpy as np
     import torch
 
-    from facebook360_dep_amd import derp, synth
+    from facebook360_dep_amd import derp, sequence, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -117,51 +117,45 @@ def main():
                                       "version": 3}
         return torch.as_tensor(a, device=torch.device("cuda", local_rank))
 
-    def temporal_level(level):
+    views = {}
+
+    def level_views(level):
         w, h = sizes[level]
-        n = w * h
         D = n_cams
-        # local views of the resident pyramid
         p, nb = g.dev_disparity(level, 0)
         disp = wrap(p, nb * D, np.float32, (D, h, w))
         p, nb = g.dev_color(level, 0)
         col = wrap(p, nb * D, np.uint16, (D, h, w, 4))
         p, nb = g.dev_mask(level, 0)
         msk = wrap(p, nb * D, np.uint8, (D, h, w))
-        key = level
-        if key not in tbuf:
-            tbuf[key] = (torch.empty((world, D, h, w), dtype=torch.float32, device=disp.device),
-                         torch.empty((world, D, h, w, 4), dtype=torch.uint16, device=disp.device),
-                         torch.empty((world, D, h, w), dtype=torch.uint8, device=disp.device),
-                         torch.empty((D, h, w), dtype=torch.float32, device=disp.device))
-        all_disp, all_col, all_msk, out = tbuf[key]
         g.synchronize()
-        if world > 1:
-            dist.all_gather_into_tensor(all_disp, disp.contiguous())
-            dist.all_gather_into_tensor(all_col.view(torch.int16), col.view(torch.int16).contiguous())
-            dist.all_gather_into_tensor(all_msk, msk.contiguous())
-        else:
-            all_disp[0].copy_(disp)
-            all_col[0].copy_(col)
-            all_msk[0].copy_(msk)
-        torch.cuda.synchronize()
-        lo, hi = max(0, rank - 2), min(world - 1, rank + 2)
+        views[level] = disp
+        return disp, col, msk
+
+    def temporal_filter(level, guides, disps, masks, offset):
+        w, h = sizes[level]
+        if level not in tbuf:
+            tbuf[level] = torch.empty((n_cams, h, w), dtype=torch.float32, device=disps[0].device)
+        out = tbuf[level]
+        torch.cuda.synchronize()  # gathered tensors were produced on torch's streams
         radius = 1  # max(ceil(1 * 0.9^level), 1), TemporalBilateralFilter.cpp:165-168
-        for d in range(D):
-            gp = [all_col[t, d].data_ptr() for t in range(lo, hi + 1)]
-            ip = [all_disp[t, d].data_ptr() for t in range(lo, hi + 1)]
-            mp = [all_msk[t, d].data_ptr() for t in range(lo, hi + 1)]
+        for d in range(n_cams):
             # sigma 0.01; weights (b, g, b) = (0.5, 1.0, 0.5) — TemporalBilateralFilter.cpp:55,176-178
-            g.temporal_filter_dev(gp, ip, mp, w, h, rank - lo, 0.01, radius, 0.5, 1.0, 0.5, out[d].data_ptr())
+            g.temporal_filter_dev([x[d].data_ptr() for x in guides], [x[d].data_ptr() for x in disps],
+                                  [x[d].data_ptr() for x in masks], w, h, offset, 0.01, radius, 0.5, 1.0, 0.5,
+                                  out[d].data_ptr())
         g.synchronize()
-        disp.copy_(out)  # "Transfer": filtered level overwrites disparity_levels/level_L (pipeline.py:397-408)
+        return out
+
+    def write_back(level, filtered):
+        # "Transfer": the filtered level overwrites disparity_levels/level_L (pipeline.py:397-408)
+        views[level].copy_(filtered)
         torch.cuda.synchronize()
 
     def step():
         if temporal:
-            for level in range(n_levels - 1, -1, -1):
-                g.process_level(level)
-                temporal_level(level)
+            sequence.run_level_schedule(rank, world, list(range(n_levels - 1, -1, -1)), g.process_level, level_views,
+                                        temporal_filter, write_back, dist=dist)
         else:
             g.process_pyramid()
 

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Freezes the oracle's output on the 'tiny' synthetic rig (4 cameras, 96x96, 3 levels) into
+tests/golden/oracle_tiny.npz: inputs are regenerated deterministically by the test; the file holds
+the expected level-0 / level-2 disparities with and without foreground masks, plus table samples.
+Run from the repo root:  python tests/golden/gen_oracle_goldens.py"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from facebook360_dep_amd import synth  # noqa: E402
+from tests import common  # noqa: E402
+
+
+def run():
+    n, res, widths = synth.config("tiny")
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    frame = synth.make_frame(rig, sizes, with_masks=True, device="cpu")
+    out = {}
+    cnt = {}
+    ref = common.oracle_pyramid(rig, sizes, frame, res, res, counters=cnt, partial_coverage=True)
+    out["plain_l0"] = np.stack(ref[0])
+    out["plain_l2"] = np.stack(ref[2])
+    out["plain_counters"] = np.array([[cnt[l]["n_cost"], cnt[l]["n_pair"]] for l in sorted(cnt)], dtype=np.int64)
+    ref = common.oracle_pyramid(rig, sizes, frame, res, res, partial_coverage=True, use_foreground_masks=True)
+    out["fg_l0"] = np.stack(ref[0])
+    L = common.oracle_level(rig, sizes, frame, 1, res, res, partial_coverage=True)
+    L.reproject_colors()
+    out["warp_1_0"] = L.proj(1, 0, "warp")
+    out["color_1_0"] = L.proj(1, 0, "color")
+    out["bias_1_0"] = L.proj(1, 0, "bias")
+    out["variance_2"] = L.variance(2)
+    out["fov_3"] = L.fov_mask(3)
+    out["input_color_l1_cam0"] = frame["color"][1][0]
+    return out
+
+
+if __name__ == "__main__":
+    data = run()
+    dst = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_tiny.npz")
+    np.savez_compressed(dst, **data)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
