@@ -1,0 +1,739 @@
+// Host-side plumbing shared by the DerpCLI / TemporalBilateralFilter / UpsampleDisparity
+// executables: gflags-style flag parsing, glog-style logging with FATAL = exit(1), a small JSON
+// reader for rig files, PNG (zlib) and PFM I/O, directory helpers. Plain C++17 + zlib; the
+// reference uses gflags, glog, folly, boost::filesystem and OpenCV imgcodecs for the same jobs.
+// All computation goes through the C-ABI in include/derp_hip.h.
+#pragma once
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/derp_hip.h"
+
+namespace cli {
+namespace fs = std::filesystem;
+
+// ---------------------------------------------------------------- logging (glog look-alike)
+inline void vlog(char sev, const char* file, int line, const std::string& msg) {
+  time_t t = time(nullptr);
+  struct tm tmv;
+  localtime_r(&t, &tmv);
+  const char* base = strrchr(file, '/');
+  fprintf(stderr, "%c%02d%02d %02d:%02d:%02d %s:%d] %s\n", sev, tmv.tm_mon + 1, tmv.tm_mday, tmv.tm_hour, tmv.tm_min,
+          tmv.tm_sec, base ? base + 1 : file, line, msg.c_str());
+}
+#define LOG_INFO(msg) cli::vlog('I', __FILE__, __LINE__, (msg))
+#define LOG_WARNING(msg) cli::vlog('W', __FILE__, __LINE__, (msg))
+// LOG(FATAL): the reference aborts; callers only look at "exit status != 0" (system_util.py:302-345)
+#define LOG_FATAL(msg)                                \
+  do {                                                \
+    cli::vlog('F', __FILE__, __LINE__, (msg));        \
+    exit(1);                                          \
+  } while (0)
+#define CHECK_MSG(cond, msg)                                             \
+  do {                                                                   \
+    if (!(cond)) {                                                       \
+      LOG_FATAL(std::string("Check failed: " #cond " ") + (msg));        \
+    }                                                                    \
+  } while (0)
+#define DERP_OK(ctx, expr)                                                            \
+  do {                                                                                \
+    if ((expr) != 0) {                                                                \
+      LOG_FATAL(std::string(#expr " failed: ") + derp_last_error(ctx));               \
+    }                                                                                 \
+  } while (0)
+
+inline std::string fmt(const char* f, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, f);
+  vsnprintf(buf, sizeof buf, f, ap);
+  va_end(ap);
+  return buf;
+}
+
+// ---------------------------------------------------------------- flags (gflags look-alike)
+struct Flags {
+  struct Def {
+    std::string type, value, help;
+  };
+  std::map<std::string, Def> defs;
+  std::vector<std::string> order;
+
+  void def(const std::string& type, const std::string& name, const std::string& dflt, const std::string& help) {
+    defs[name] = {type, dflt, help};
+    order.push_back(name);
+  }
+  void str(const std::string& n, const std::string& d, const std::string& h) { def("string", n, d, h); }
+  void i32(const std::string& n, int d, const std::string& h) { def("int32", n, std::to_string(d), h); }
+  void dbl(const std::string& n, double d, const std::string& h) {
+    std::ostringstream ss;
+    ss.precision(17);
+    ss << d;
+    def("double", n, ss.str(), h);
+  }
+  void boolean(const std::string& n, bool d, const std::string& h) { def("bool", n, d ? "true" : "false", h); }
+
+  std::string s(const std::string& n) const { return defs.at(n).value; }
+  int i(const std::string& n) const { return atoi(defs.at(n).value.c_str()); }
+  double d(const std::string& n) const { return atof(defs.at(n).value.c_str()); }
+  bool b(const std::string& n) const {
+    const std::string& v = defs.at(n).value;
+    return v == "true" || v == "1" || v == "t" || v == "yes" || v == "y";
+  }
+  void set(const std::string& n, const std::string& v) { defs.at(n).value = v; }
+
+  void set_checked(const std::string& name, const std::string& value, bool from_file) {
+    auto it = defs.find(name);
+    if (it == defs.end()) {
+      if (from_file) {
+        return;  // gflags --undefok-like leniency for shared flagfiles
+      }
+      fprintf(stderr, "ERROR: unknown command line flag '%s'\n", name.c_str());
+      exit(1);
+    }
+    if (it->second.type == "int32" || it->second.type == "double") {
+      char* end = nullptr;
+      strtod(value.c_str(), &end);
+      if (value.empty() || (end && *end)) {
+        fprintf(stderr, "ERROR: illegal value '%s' specified for %s flag '%s'\n", value.c_str(),
+                it->second.type.c_str(), name.c_str());
+        exit(1);
+      }
+    }
+    it->second.value = value;
+  }
+
+  void parse_tokens(const std::vector<std::string>& toks, bool from_file) {
+    for (size_t k = 0; k < toks.size(); ++k) {
+      std::string a = toks[k];
+      if (a.rfind("--", 0) == 0) {
+        a = a.substr(2);
+      } else if (a.rfind("-", 0) == 0) {
+        a = a.substr(1);
+      } else {
+        continue;
+      }
+      std::string name = a, value;
+      bool has_value = false;
+      const size_t eq = a.find('=');
+      if (eq != std::string::npos) {
+        name = a.substr(0, eq);
+        value = a.substr(eq + 1);
+        has_value = true;
+      }
+      if (name == "flagfile") {
+        if (!has_value && k + 1 < toks.size()) {
+          value = toks[++k];
+        }
+        parse_file(value);
+        continue;
+      }
+      if (name == "help" || name == "helpshort") {
+        usage();
+        exit(0);
+      }
+      auto it = defs.find(name);
+      if (it == defs.end() && name.rfind("no", 0) == 0 && defs.count(name.substr(2)) &&
+          defs[name.substr(2)].type == "bool") {
+        defs[name.substr(2)].value = "false";
+        continue;
+      }
+      if (it != defs.end() && it->second.type == "bool" && !has_value) {
+        it->second.value = "true";
+        continue;
+      }
+      if (!has_value) {
+        if (k + 1 < toks.size()) {
+          value = toks[++k];
+        } else if (from_file) {
+          continue;  // test flagfiles list bare I/O flag names (res/test/derp_cli.flags)
+        } else {
+          fprintf(stderr, "ERROR: flag '--%s' is missing its argument\n", name.c_str());
+          exit(1);
+        }
+      }
+      set_checked(name, value, from_file);
+    }
+  }
+  void parse_file(const std::string& path) {
+    std::ifstream f(path);
+    if (!f.good()) {
+      fprintf(stderr, "ERROR: can't open flagfile %s\n", path.c_str());
+      exit(1);
+    }
+    std::vector<std::string> toks;
+    std::string line;
+    while (std::getline(f, line)) {
+      const size_t a = line.find_first_not_of(" \t\r");
+      if (a == std::string::npos || line[a] == '#') {
+        continue;
+      }
+      const size_t b = line.find_last_not_of(" \t\r");
+      // one flag per line: keep "--name=value" / "--name" whole
+      parse_tokens({line.substr(a, b - a + 1)}, true);
+    }
+  }
+  std::string usage_msg;
+  void usage() const {
+    printf("%s\n", usage_msg.c_str());
+    for (const auto& n : order) {
+      const Def& d = defs.at(n);
+      printf("    -%s (%s) type: %s default: %s\n", n.c_str(), d.help.c_str(), d.type.c_str(), d.value.c_str());
+    }
+  }
+  void parse(int argc, char** argv) {
+    // glog flags the pipeline passes (res/flags/*.flags): accepted, logging always goes to stderr
+    str("log_dir", "", "glog: directory for log files (accepted; logs go to stderr)");
+    boolean("alsologtostderr", false, "glog: accepted");
+    boolean("logtostderr", false, "glog: accepted");
+    i32("stderrthreshold", 2, "glog: accepted");
+    i32("v", 0, "glog: accepted");
+    i32("minloglevel", 0, "glog: accepted");
+    std::vector<std::string> toks(argv + 1, argv + argc);
+    parse_tokens(toks, false);
+    // SystemUtil.cpp:78-97: log every project flag at start
+    for (const auto& n : order) {
+      LOG_INFO("--" + n + "=" + defs.at(n).value);
+    }
+  }
+};
+
+// ---------------------------------------------------------------- JSON (rig files only)
+struct Json {
+  enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+  double num = 0;
+  bool boolean = false;
+  std::string str;
+  std::vector<Json> arr;
+  std::vector<std::pair<std::string, Json>> obj;
+  const Json* find(const std::string& k) const {
+    for (const auto& kv : obj) {
+      if (kv.first == k) {
+        return &kv.second;
+      }
+    }
+    return nullptr;
+  }
+  const Json& at(const std::string& k) const {
+    const Json* j = find(k);
+    if (!j) {
+      LOG_FATAL("rig JSON: missing key '" + k + "'");
+    }
+    return *j;
+  }
+};
+struct JsonParser {
+  const std::string& s;
+  size_t p = 0;
+  explicit JsonParser(const std::string& text) : s(text) {}
+  void ws() {
+    while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) {
+      ++p;
+    }
+  }
+  [[noreturn]] void bad(const char* what) { LOG_FATAL(fmt("rig JSON parse error at offset %zu: %s", p, what)); }
+  Json value() {
+    ws();
+    if (p >= s.size()) {
+      bad("unexpected end");
+    }
+    Json j;
+    const char c = s[p];
+    if (c == '{') {
+      j.kind = Json::Obj;
+      ++p;
+      ws();
+      if (s[p] == '}') {
+        ++p;
+        return j;
+      }
+      for (;;) {
+        ws();
+        Json k = value();
+        if (k.kind != Json::Str) {
+          bad("object key must be a string");
+        }
+        ws();
+        if (s[p] != ':') {
+          bad("expected ':'");
+        }
+        ++p;
+        j.obj.emplace_back(k.str, value());
+        ws();
+        if (s[p] == ',') {
+          ++p;
+          continue;
+        }
+        if (s[p] == '}') {
+          ++p;
+          break;
+        }
+        bad("expected ',' or '}'");
+      }
+    } else if (c == '[') {
+      j.kind = Json::Arr;
+      ++p;
+      ws();
+      if (s[p] == ']') {
+        ++p;
+        return j;
+      }
+      for (;;) {
+        j.arr.push_back(value());
+        ws();
+        if (s[p] == ',') {
+          ++p;
+          continue;
+        }
+        if (s[p] == ']') {
+          ++p;
+          break;
+        }
+        bad("expected ',' or ']'");
+      }
+    } else if (c == '"') {
+      j.kind = Json::Str;
+      ++p;
+      while (p < s.size() && s[p] != '"') {
+        if (s[p] == '\\' && p + 1 < s.size()) {
+          ++p;
+          switch (s[p]) {
+            case 'n': j.str += '\n'; break;
+            case 't': j.str += '\t'; break;
+            case 'u': p += 4; j.str += '?'; break;
+            default: j.str += s[p];
+          }
+        } else {
+          j.str += s[p];
+        }
+        ++p;
+      }
+      ++p;
+    } else if (s.compare(p, 4, "true") == 0) {
+      j.kind = Json::Bool;
+      j.boolean = true;
+      p += 4;
+    } else if (s.compare(p, 5, "false") == 0) {
+      j.kind = Json::Bool;
+      p += 5;
+    } else if (s.compare(p, 4, "null") == 0) {
+      p += 4;
+    } else {
+      char* end = nullptr;
+      j.kind = Json::Num;
+      j.num = strtod(s.c_str() + p, &end);
+      if (end == s.c_str() + p) {
+        bad("unexpected character");
+      }
+      p = end - s.c_str();
+    }
+    return j;
+  }
+};
+
+inline std::string read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary);
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+
+// Camera::loadRig (Camera.cpp:244-258) -> the C-ABI's camera descriptions
+inline std::vector<derp_camera_desc> load_rig(const std::string& path) {
+  const std::string text = read_file(path);
+  CHECK_MSG(!text.empty(), "could not read JSON file: " + path);
+  JsonParser jp(text);
+  const Json root = jp.value();
+  std::vector<derp_camera_desc> out;
+  for (const Json& c : root.at("cameras").arr) {
+    derp_camera_desc d;
+    memset(&d, 0, sizeof d);
+    const Json& ver = c.at("version");
+    CHECK_MSG((ver.kind == Json::Num ? ver.num : atof(ver.str.c_str())) >= 1.0, "camera version");
+    snprintf(d.id, sizeof d.id, "%s", c.at("id").str.c_str());
+    const std::string type = c.at("type").str;
+    d.type = type == "FTHETA" ? DERP_FTHETA : type == "RECTILINEAR" ? DERP_RECTILINEAR
+        : type == "EQUISOLID" ? DERP_EQUISOLID : type == "ORTHOGRAPHIC" ? DERP_ORTHOGRAPHIC : -1;
+    CHECK_MSG(d.type >= 0, "unexpected camera type " + type);
+    auto vec = [&](const char* key, double* dst, size_t n) {
+      const Json& a = c.at(key);
+      CHECK_MSG(a.arr.size() == n, std::string("bad vector ") + key);
+      for (size_t i = 0; i < n; ++i) {
+        dst[i] = a.arr[i].num;
+      }
+    };
+    vec("origin", d.origin, 3);
+    vec("forward", d.forward, 3);
+    vec("up", d.up, 3);
+    vec("right", d.right, 3);
+    vec("resolution", d.resolution, 2);
+    vec("focal", d.focal, 2);
+    if (c.find("principal")) {
+      d.has_principal = 1;
+      vec("principal", d.principal, 2);
+    }
+    if (const Json* dist = c.find("distortion")) {
+      CHECK_MSG(dist->arr.size() <= 3, "bad distortion");
+      d.has_distortion = 1;
+      for (size_t i = 0; i < dist->arr.size(); ++i) {
+        d.distortion[i] = dist->arr[i].num;
+      }
+    }
+    if (const Json* fov = c.find("fov")) {
+      d.has_fov = 1;
+      d.fov = fov->num;
+    }
+    out.push_back(d);
+  }
+  return out;
+}
+
+// image_util::filterDestinations (ImageUtil.cpp:110-125)
+inline std::vector<derp_camera_desc> filter_destinations(const std::vector<derp_camera_desc>& rig,
+                                                         const std::string& destinations) {
+  if (destinations.empty()) {
+    return rig;
+  }
+  std::vector<derp_camera_desc> out;
+  std::stringstream ss(destinations);
+  std::string dest;
+  while (std::getline(ss, dest, ',')) {
+    for (const auto& cam : rig) {
+      if (dest == cam.id) {
+        out.push_back(cam);
+      }
+    }
+  }
+  return out;
+}
+
+// ---------------------------------------------------------------- filesystem helpers
+inline bool is_hidden(const fs::path& p) {
+  const std::string n = p.filename().string();
+  return !n.empty() && n[0] == '.';
+}
+inline std::vector<fs::path> visible_files_sorted(const fs::path& dir) {
+  std::vector<fs::path> r;
+  if (fs::is_directory(dir)) {
+    for (const auto& e : fs::directory_iterator(dir)) {
+      if (e.is_regular_file() && !is_hidden(e.path())) {
+        r.push_back(e.path());
+      }
+    }
+  }
+  std::sort(r.begin(), r.end());
+  return r;
+}
+inline std::string first_extension(const fs::path& dir) {  // FilesystemUtil.h:91-95
+  const auto files = visible_files_sorted(dir);
+  CHECK_MSG(!files.empty(), "no visible files in " + dir.string());
+  return files[0].extension().string();
+}
+inline std::string zero_pad(int x, int n = 6) {  // image_util::intToStringZeroPad
+  char b[32];
+  snprintf(b, sizeof b, "%0*d", n, x);
+  return b;
+}
+inline fs::path image_path(const fs::path& dir, const std::string& cam, const std::string& frame,
+                           const std::string& ext = "") {  // ImageUtil.h:48-56
+  const fs::path camDir = dir / cam;
+  return camDir / (frame + (ext.empty() ? first_extension(camDir) : ext));
+}
+// verifyImagePaths (ImageUtil.cpp:63-95)
+inline void verify_image_paths(const fs::path& dir, const std::vector<derp_camera_desc>& rig, const std::string& first,
+                               const std::string& last) {
+  int a = 0, b = 0;
+  try {
+    a = std::stoi(first);
+    b = std::stoi(last);
+  } catch (...) {
+    LOG_FATAL("Invalid frame name: " + first + " / " + last);
+  }
+  CHECK_MSG(a <= b, "first <= last");
+  CHECK_MSG(!rig.empty(), "rig.size() > 0");
+  const std::string ext = first_extension(dir / rig[0].id);
+  for (const auto& cam : rig) {
+    for (int f = a; f <= b; ++f) {
+      const fs::path p = dir / cam.id / (zero_pad(f) + ext);
+      CHECK_MSG(fs::is_regular_file(p), "Missing file: " + p.string());
+    }
+  }
+}
+
+// ---------------------------------------------------------------- PFM (CvUtil.cpp:39-73)
+inline void write_pfm(const fs::path& path, const float* m, int w, int h) {
+  std::ofstream f(path, std::ios::binary);
+  f << "Pf\n" << w << " " << h << "\n-1.0\n";
+  f.write(reinterpret_cast<const char*>(m), (size_t)w * h * sizeof(float));
+  CHECK_MSG(f.good(), "failed to save image: " + path.string());
+}
+inline bool pfm_size(const fs::path& path, int& w, int& h) {
+  std::ifstream f(path, std::ios::binary);
+  std::string magic;
+  std::getline(f, magic);
+  if (magic != "Pf") {
+    return false;
+  }
+  f >> w >> h;
+  return f.good();
+}
+inline std::vector<float> read_pfm(const fs::path& path, int& w, int& h) {
+  std::ifstream f(path, std::ios::binary);
+  CHECK_MSG(f.good(), "cannot load file: " + path.string());
+  std::string magic;
+  std::getline(f, magic);
+  CHECK_MSG(magic == "Pf", "expected 'Pf' in 1-channel .pfm file header: " + path.string());
+  double endian;
+  f >> w >> h >> endian;
+  CHECK_MSG(endian <= 0.0, "only little endian .pfm files supported: " + path.string());
+  f.ignore();
+  std::vector<float> m((size_t)w * h);
+  f.read(reinterpret_cast<char*>(m.data()), m.size() * sizeof(float));
+  return m;
+}
+
+// ---------------------------------------------------------------- PNG via zlib
+struct Png {
+  int w = 0, h = 0, channels = 0, bitdepth = 0;
+  std::vector<uint16_t> px;  // interleaved, file channel order (RGB[A] / gray), 8-bit widened as-is
+};
+inline uint32_t be32(const unsigned char* p) {
+  return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3];
+}
+inline bool png_size(const fs::path& path, int& w, int& h) {
+  std::ifstream f(path, std::ios::binary);
+  unsigned char hd[24];
+  f.read(reinterpret_cast<char*>(hd), 24);
+  if (!f.good() || memcmp(hd, "\x89PNG\r\n\x1a\n", 8) != 0) {
+    return false;
+  }
+  w = be32(hd + 16);
+  h = be32(hd + 20);
+  return true;
+}
+inline Png read_png(const fs::path& path) {
+  const std::string data = read_file(path.string());
+  CHECK_MSG(data.size() > 8 && memcmp(data.data(), "\x89PNG\r\n\x1a\n", 8) == 0, "failed to load image: " + path.string());
+  const unsigned char* d = reinterpret_cast<const unsigned char*>(data.data());
+  size_t pos = 8;
+  std::string idat;
+  Png img;
+  int color_type = -1, interlace = 0;
+  while (pos + 12 <= data.size()) {
+    const uint32_t n = be32(d + pos);
+    const std::string tag(data, pos + 4, 4);
+    if (tag == "IHDR") {
+      img.w = be32(d + pos + 8);
+      img.h = be32(d + pos + 12);
+      img.bitdepth = d[pos + 16];
+      color_type = d[pos + 17];
+      interlace = d[pos + 20];
+    } else if (tag == "IDAT") {
+      idat.append(data, pos + 8, n);
+    } else if (tag == "IEND") {
+      break;
+    }
+    pos += 12 + n;
+  }
+  CHECK_MSG(!interlace && (img.bitdepth == 8 || img.bitdepth == 16) && (color_type == 0 || color_type == 2 || color_type == 6),
+            "unsupported PNG flavour: " + path.string());
+  img.channels = color_type == 0 ? 1 : color_type == 2 ? 3 : 4;
+  const int bpp = img.channels * img.bitdepth / 8;
+  const size_t stride = (size_t)img.w * bpp;
+  std::vector<unsigned char> raw((stride + 1) * img.h);
+  uLongf rawLen = raw.size();
+  CHECK_MSG(uncompress(raw.data(), &rawLen, reinterpret_cast<const Bytef*>(idat.data()), idat.size()) == Z_OK &&
+                rawLen == raw.size(),
+            "corrupt PNG: " + path.string());
+  std::vector<unsigned char> cur(stride), prev(stride, 0);
+  img.px.resize((size_t)img.w * img.h * img.channels);
+  for (int y = 0; y < img.h; ++y) {
+    const unsigned char* line = raw.data() + (stride + 1) * y;
+    const int ft = line[0];
+    for (size_t i = 0; i < stride; ++i) {
+      const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
+      int pred = 0;
+      switch (ft) {
+        case 0: pred = 0; break;
+        case 1: pred = a; break;
+        case 2: pred = b; break;
+        case 3: pred = (a + b) >> 1; break;
+        case 4: {
+          const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+          break;
+        }
+        default: LOG_FATAL("bad PNG filter: " + path.string());
+      }
+      cur[i] = (unsigned char)(line[1 + i] + pred);
+    }
+    uint16_t* o = &img.px[(size_t)y * img.w * img.channels];
+    for (int i = 0; i < img.w * img.channels; ++i) {
+      o[i] = img.bitdepth == 16 ? uint16_t((cur[2 * i] << 8) | cur[2 * i + 1]) : cur[i];
+    }
+    prev.swap(cur);
+  }
+  return img;
+}
+inline void write_png(const fs::path& path, const uint16_t* px, int w, int h, int channels, int bitdepth) {
+  const int bpp = channels * bitdepth / 8;
+  const size_t stride = (size_t)w * bpp;
+  std::vector<unsigned char> raw((stride + 1) * h);
+  for (int y = 0; y < h; ++y) {
+    unsigned char* line = raw.data() + (stride + 1) * y;
+    line[0] = 0;
+    for (int i = 0; i < w * channels; ++i) {
+      const uint16_t v = px[(size_t)y * w * channels + i];
+      if (bitdepth == 16) {
+        line[1 + 2 * i] = v >> 8;
+        line[2 + 2 * i] = v & 255;
+      } else {
+        line[1 + i] = (unsigned char)v;
+      }
+    }
+  }
+  uLongf clen = compressBound(raw.size());
+  std::vector<unsigned char> comp(clen);
+  CHECK_MSG(compress2(comp.data(), &clen, raw.data(), raw.size(), 3) == Z_OK, "PNG deflate failed");
+  std::ofstream f(path, std::ios::binary);
+  auto chunk = [&](const char* tag, const unsigned char* body, uint32_t n) {
+    unsigned char len[4] = {(unsigned char)(n >> 24), (unsigned char)(n >> 16), (unsigned char)(n >> 8), (unsigned char)n};
+    f.write(reinterpret_cast<char*>(len), 4);
+    f.write(tag, 4);
+    if (n) {
+      f.write(reinterpret_cast<const char*>(body), n);
+    }
+    uLong crc = crc32(0L, reinterpret_cast<const Bytef*>(tag), 4);
+    if (n) {
+      crc = crc32(crc, body, n);
+    }
+    unsigned char cb[4] = {(unsigned char)(crc >> 24), (unsigned char)(crc >> 16), (unsigned char)(crc >> 8), (unsigned char)crc};
+    f.write(reinterpret_cast<char*>(cb), 4);
+  };
+  f.write("\x89PNG\r\n\x1a\n", 8);
+  unsigned char ihdr[13] = {(unsigned char)(w >> 24), (unsigned char)(w >> 16), (unsigned char)(w >> 8), (unsigned char)w,
+                            (unsigned char)(h >> 24), (unsigned char)(h >> 16), (unsigned char)(h >> 8), (unsigned char)h,
+                            (unsigned char)bitdepth, (unsigned char)(channels == 1 ? 0 : channels == 3 ? 2 : 6), 0, 0, 0};
+  chunk("IHDR", ihdr, 13);
+  chunk("IDAT", comp.data(), (uint32_t)clen);
+  chunk("IEND", nullptr, 0);
+  CHECK_MSG(f.good(), "failed to save image: " + path.string());
+}
+
+// cv_util::loadImage<Vec3w> (CvUtil.h:196-284): IMREAD_UNCHANGED -> 16U (8-bit x257) -> BGR
+inline std::vector<uint16_t> load_color_bgr16(const fs::path& path, int& w, int& h) {
+  const Png p = read_png(path);
+  w = p.w;
+  h = p.h;
+  std::vector<uint16_t> out((size_t)w * h * 3);
+  const int mul = p.bitdepth == 8 ? 257 : 1;
+  for (size_t i = 0; i < (size_t)w * h; ++i) {
+    if (p.channels == 1) {
+      out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = p.px[i] * mul;
+    } else {
+      out[3 * i + 0] = p.px[p.channels * i + 2] * mul;  // B
+      out[3 * i + 1] = p.px[p.channels * i + 1] * mul;  // G
+      out[3 * i + 2] = p.px[p.channels * i + 0] * mul;  // R
+    }
+  }
+  return out;
+}
+// cv_util::loadImage<bool> (CvUtil.h:235-239): to 8-bit, threshold > 127 -> 1
+inline std::vector<uint8_t> load_mask(const fs::path& path, int& w, int& h) {
+  const Png p = read_png(path);
+  w = p.w;
+  h = p.h;
+  std::vector<uint8_t> out((size_t)w * h);
+  for (size_t i = 0; i < out.size(); ++i) {
+    unsigned v = p.px[(size_t)p.channels * i];
+    if (p.bitdepth == 16) {
+      v = (unsigned)lrintf(v * (255.0f / 65535.0f));  // convertTo(CV_8U, 255/65535): saturate_cast rounds
+    }
+    out[i] = v > 127;
+  }
+  return out;
+}
+// cv_util::loadImage<float>: PFM as is; PNG scaled to [0,1]
+inline std::vector<float> load_float(const fs::path& path, int& w, int& h) {
+  if (path.extension() == ".pfm") {
+    return read_pfm(path, w, h);
+  }
+  const Png p = read_png(path);
+  w = p.w;
+  h = p.h;
+  std::vector<float> out((size_t)w * h);
+  const float scale = 1.0f / (p.bitdepth == 16 ? 65535.0f : 255.0f);
+  for (size_t i = 0; i < out.size(); ++i) {
+    out[i] = p.px[(size_t)p.channels * i] * scale;
+  }
+  return out;
+}
+inline bool image_size(const fs::path& path, int& w, int& h) {
+  return path.extension() == ".pfm" ? pfm_size(path, w, h) : png_size(path, w, h);
+}
+// cv_util::convertTo<uint16_t>(float disparity): x65535, saturate (NaN -> 0), PyramidLevel.h:517-519
+inline void write_disparity_png(const fs::path& path, const float* m, int w, int h) {
+  std::vector<uint16_t> px((size_t)w * h);
+  for (size_t i = 0; i < px.size(); ++i) {
+    const float v = m[i] * 65535.0f;
+    px[i] = !(v == v) ? 0 : v <= 0 ? 0 : v >= 65535.f ? 65535 : (uint16_t)lrintf(v);
+  }
+  write_png(path, px.data(), w, h, 1, 16);
+}
+
+// getPyramidLevelSizes (Derp.cpp:72-99): level_N -> size of the first image found under it
+inline void pyramid_level_sizes(std::map<int, std::pair<int, int>>& sizes, const fs::path& dir) {
+  if (!fs::exists(dir)) {
+    return;
+  }
+  for (const auto& e : fs::directory_iterator(dir)) {
+    if (!e.is_directory() || is_hidden(e.path())) {
+      continue;
+    }
+    const std::string name = e.path().filename().string();
+    if (name.rfind("level_", 0) != 0) {
+      continue;
+    }
+    std::vector<fs::path> files;
+    for (const auto& f : fs::recursive_directory_iterator(e.path())) {
+      if (f.is_regular_file() && !is_hidden(f.path()) && f.path().extension() != ".tar") {
+        files.push_back(f.path());
+      }
+    }
+    if (files.empty()) {
+      continue;
+    }
+    std::sort(files.begin(), files.end());
+    int w, h;
+    if (image_size(files[0], w, h)) {
+      sizes[std::stoi(name.substr(6))] = {w, h};
+    }
+  }
+}
+
+struct Timer {
+  timespec t0;
+  Timer() { clock_gettime(CLOCK_MONOTONIC, &t0); }
+  double s() const {
+    timespec t1;
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+  }
+};
+
+}  // namespace cli

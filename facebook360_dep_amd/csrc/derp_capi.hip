@@ -548,6 +548,9 @@ int check_level(derp_ctx* c, int level) {
   if (level < 0 || level >= c->numLevels) {
     return fail(c, "level %d out of range [0, %d)", level, c->numLevels);
   }
+  if (c->LW[level] <= 0 || c->LH[level] <= 0) {
+    return fail(c, "level %d was declared absent in derp_set_pyramid", level);
+  }
   return 0;
 }
 
@@ -859,6 +862,9 @@ int derp_set_pyramid(derp_ctx* c, int num_levels, const int* widths, const int* 
   size_t nmax = 0;
   for (int l = 0; l < num_levels; ++l) {
     const size_t n = npx(c, l);
+    if (n == 0) {
+      continue;  // level not present / not needed by this run
+    }
     nmax = std::max(nmax, n);
     ALLOC(c, c->pyrColor[l], n * c->S * sizeof(ushort4));
     ALLOC(c, c->pyrFg[l], n * c->S);
@@ -1137,6 +1143,26 @@ int derp_debug_download(derp_ctx* c, int d, int s, int which, void* out) {
 }
 
 // ---- sibling binaries' kernels, host-pointer convenience forms ----
+int derp_fov_mask(derp_ctx* c, int d, int w, int h, uint8_t* out) {
+  if (!c || !out || d < 0 || d >= c->D || w <= 0 || h <= 0) {
+    return fail(c, "bad arguments");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf m;
+  if (m.ensure((size_t)w * h)) {
+    return fail(c, "out of device memory");
+  }
+  hipLaunchKernelGGL(k_fov_mask, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>() + d, w, h,
+                     m.as<uint8_t>());
+  int rc = 0;
+  if (hipStreamSynchronize(c->stream) != hipSuccess ||
+      hipMemcpy(out, m.p, (size_t)w * h, hipMemcpyDeviceToHost) != hipSuccess) {
+    rc = fail(c, "HIP error in derp_fov_mask: %s", hipGetErrorString(hipGetLastError()));
+  }
+  m.release();
+  return rc;
+}
+
 int derp_upsample_disparity(derp_ctx* c, int d, const float* disp, int w, int h, const float* bg_disp_up,
                             const uint8_t* fg_mask, const uint8_t* fg_mask_up, int w_up, int h_up, int use_fg,
                             float* out) {

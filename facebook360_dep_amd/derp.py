@@ -42,7 +42,7 @@ EXPORTS = [
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
     "derp_stage_ping_pong", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
-    "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
+    "derp_fov_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query",
     "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
@@ -261,6 +261,11 @@ class Derp:
         return out
 
     # ---- sibling kernels
+    def fov_mask(self, d, w, h):
+        out = np.zeros((h, w), dtype=np.uint8)
+        self._ck(lib().derp_fov_mask(self.h, d, w, h, _p(out)))
+        return out
+
     def upsample_disparity(self, d, disp, w_up, h_up, bg_up=None, fg=None, fg_up=None):
         disp = np.ascontiguousarray(disp, dtype=np.float32)
         h, w = disp.shape

@@ -310,6 +310,7 @@ def write_dataset(root, rig, frames, sizes, seed=360, with_masks=False):
                     d = os.path.join(root, "video", "foreground_masks_levels", "level_%d" % li, cam["id"])
                     os.makedirs(d, exist_ok=True)
                     dio.write_png8(os.path.join(d, name + ".png"), fr["masks"][li][ci] * 255)
-                    d = os.path.join(root, "background", "disparity_levels", "level_%d" % li, cam["id"])
-                    os.makedirs(d, exist_ok=True)
-                    dio.write_pfm(os.path.join(d, "000000.pfm"), fr["bg_disp"][li][ci])
+                    if fi == frames[0]:  # one static background frame (--background_frame=000000)
+                        d = os.path.join(root, "background", "disparity_levels", "level_%d" % li, cam["id"])
+                        os.makedirs(d, exist_ok=True)
+                        dio.write_pfm(os.path.join(d, "000000.pfm"), fr["bg_disp"][li][ci])

@@ -126,6 +126,8 @@ int derp_cost_map(derp_ctx* ctx, int dst, const float* disp, float* cost, float*
 int derp_debug_download(derp_ctx* ctx, int dst, int src, int which, void* out);
 
 /* ---- the sibling binaries' kernels ------------------------------------------------------- */
+/* generateFovMasks for one destination camera at an arbitrary size (DerpUtil.cpp:259-276) */
+int derp_fov_mask(derp_ctx* ctx, int dst, int w, int h, uint8_t* out);
 /* upsampleDisparities for one camera (UpsampleDisparityLib.cpp:98-182). fg_mask / fg_mask_up /
  * bg_disp_up may be NULL when use_foreground_masks == 0. `dst` selects the FOV mask camera. */
 int derp_upsample_disparity(derp_ctx* ctx, int dst, const float* disp, int w, int h,
