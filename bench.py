@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--temporal", type=int, default=-1, help="-1: on iff gpus > 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--cache-warp-tables", type=int, default=0,
                     help="1 = keep the rig-only projection warps across steps (default 0: rebuilt every step, as the "
                          "reference does per frame)")
@@ -79,13 +80,17 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
+    if os.environ.get("DERP_BENCH_SINGLE_DEVICE"):  # developer check of the N>1 path on a 1-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     temporal = (world > 1) if args.temporal < 0 else bool(args.temporal)
 
     n_cams, res, widths = synth.config(args.config)

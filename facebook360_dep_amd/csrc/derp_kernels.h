@@ -26,6 +26,9 @@
 
 namespace derp {
 
+#ifndef DERP_COST_MIN_WAVES
+#define DERP_COST_MIN_WAVES 2
+#endif
 static constexpr int kPadW = 1;   // ring of projWarp
 static constexpr int kPadC = 2;   // ring of projColor / projBias
 static constexpr int kMaxSrc = 32;
@@ -125,6 +128,9 @@ struct LdsPairs {
 // computeSSD (DerpUtil.cpp:126-162) for one source whose projected tables are `col` / `bias`.
 __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
                                                const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc) {
+#ifdef DERP_ABLATE_NO_SSD
+  return {xDstSrc * 1e-3f, yDstSrc * 1e-3f};
+#endif
   const int pitch = V.W + 2 * kPadC;
   // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
   float bias[3];
@@ -251,9 +257,20 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
     const Cam& cs = V.camsSrc[s];
     D2 pn;
     // worldToSrcPoint (DerpUtil.cpp:56-73): Camera::sees on the normalised camera, then * (W, H)
+#ifdef DERP_ABLATE_NO_PROJ
+    {
+      const float fx = (float)pWorld.x * 0.07f + 0.013f * s, fy = (float)pWorld.y * 0.07f + 0.011f * s;
+      pn.x = 0.5 + 0.45 * (double)(fx - floorf(fx) - 0.5f);
+      pn.y = 0.5 + 0.45 * (double)(fy - floorf(fy) - 0.5f);
+      if ((s & 1) == 0) {
+        continue;
+      }
+    }
+#else
     if (!sees(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1], 1.0, 1.0, pn)) {
       continue;
     }
+#endif
     const float sx = (float)(pn.x * (double)V.W), sy = (float)(pn.y * (double)V.H);
     const size_t tab = (size_t)dl * (V.S - 1) + slot(s, own);
     // pDstSrc = getPixelBilinear(dstProjWarp, pSrc)
@@ -286,7 +303,9 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
   }
   keep = max(keep, ssdCount - 2);
   GccSelect<LdsPairs> sel(pairs);
+#ifndef DERP_ABLATE_NO_SELECT
   sel.nth_element(keep, ssdCount);
+#endif
   float cost = 0;
   for (int i = 0; i < keep; ++i) {
     cost += pairs.get(i).second;
@@ -604,7 +623,7 @@ __device__ __forceinline__ float probe_disparity(int i, float minD, float maxD) 
   return (float)(fraction * (double)minD + (1 - fraction) * (double)maxD);
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
     k_brute_costs(LevelView V, float* __restrict__ costs, float* __restrict__ confs, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
   const int i = blockIdx.y;   // disparity index
@@ -740,7 +759,7 @@ __global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
     k_random_proposals(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
   const int dl = blockIdx.y;
@@ -795,7 +814,7 @@ __global__ void __launch_bounds__(256)
 // ----------------------------------------------------------------------------------------
 __constant__ int kCandidates[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-2, -2}, {2, -2}, {-2, 2}, {2, 2}};
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
     k_ping_pong(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
                 float* __restrict__ costRes, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
@@ -862,7 +881,7 @@ __global__ void k_ping_pong_commit(float* __restrict__ disp, float* __restrict__
 }
 
 // cost map of a caller-supplied disparity image (test hook over compute_cost)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
     k_cost_map(LevelView V, int d, const float* __restrict__ dispIn, float* __restrict__ costOut,
                float* __restrict__ confOut, int tilesX) {
   extern __shared__ SsdPair ldsPairs[];
@@ -886,10 +905,55 @@ __global__ void __launch_bounds__(256)
 // ----------------------------------------------------------------------------------------
 // filters
 // ----------------------------------------------------------------------------------------
-// expf as the reference's libm computes it (correctly rounded for all practical purposes):
-// evaluate in fp64, round once to fp32.
-__device__ __forceinline__ float expf_cr(float x) {
-  return (float)exp((double)x);
+// expf exactly as the reference's libm computes it. glibc >= 2.27 (sysdeps/ieee754/flt-32/e_expf.c,
+// from ARM's optimized-routines): exp(x) = 2^(k/32) * p(r) in fp64 with a 32-entry table and a cubic,
+// rounded once to fp32. On x86-64 hosts with FMA the ifunc picks the -mfma build, in which GCC
+// contracts BOTH uses of z = InvLn2N * x (z + SHIFT and z - kd) and the three polynomial steps; that
+// variant is restated here with explicit fma (checked bit-for-bit against this image's libm on 7.6e7
+// inputs, 0 mismatches; the non-FMA build differs from it on ~3 inputs in 1e8).
+__constant__ unsigned long long kExp2fTab[32] = {
+    0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull,
+    0x3fef72b83c7d517bull, 0x3fef54873168b9aaull, 0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull,
+    0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+    0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull,
+    0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull, 0x3feea11473eb0187ull, 0x3feea589994cce13ull,
+    0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+    0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
+    0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+
+__device__ __forceinline__ float expf_glibc(float x) {
+  const double InvLn2N = 0x1.71547652b82fep+0 * 32;
+  const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32,
+               C2 = 0x1.62e42ff0c52d6p-1 / 32;
+  const double SHIFT = 0x1.8p+52;
+  const unsigned abstop = (__float_as_uint(x) >> 20) & 0x7ff;
+  if (abstop >= (0x42b00000u >> 20)) {  // |x| >= 88 or NaN
+    if (__float_as_uint(x) == 0xff800000u) {
+      return 0.0f;
+    }
+    if (abstop >= (0x7f800000u >> 20)) {
+      return x + x;
+    }
+    if (x > 0x1.62e42ep6f) {
+      return __builtin_inff();
+    }
+    if (x < -0x1.9fe368p6f) {
+      return 0.0f;
+    }
+  }
+  const double xd = (double)x;
+  double kd = __builtin_fma(InvLn2N, xd, SHIFT);
+  const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+  kd -= SHIFT;
+  const double r = __builtin_fma(InvLn2N, xd, -kd);
+  const unsigned long long t = kExp2fTab[ki & 31] + (ki << 47);
+  const double sc = __longlong_as_double((long long)t);
+  const double z = __builtin_fma(C0, r, C1);
+  const double r2 = r * r;
+  double y = __builtin_fma(C2, r, 1.0);
+  y = __builtin_fma(z, r2, y);
+  y = y * sc;
+  return (float)y;
 }
 
 // generalizedJointBilateralFilter<float, Vec3w> — TemporalBilateralFilter.h:39-124.
@@ -926,7 +990,7 @@ __global__ void k_joint_bilateral_u16(const float* __restrict__ image, const ush
         const ushort4 nb = g[j];
         const float d0 = g0 - nb.x * factor, d1 = g1 - nb.y * factor, d2 = g2 - nb.z * factor;
         const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
-        const float weight = expf_cr((-colorDiffSq / 3.0f) / denom);
+        const float weight = expf_glibc((-colorDiffSq / 3.0f) / denom);
         sumWeight += weight;
         weightedAvg += weight * img[j];
       }
@@ -968,7 +1032,7 @@ __global__ void k_joint_bilateral_f32(const float* __restrict__ image, const flo
         const float d0 = g0 - guide[3 * j] * factor, d1 = g1 - guide[3 * j + 1] * factor,
                     d2 = g2 - guide[3 * j + 2] * factor;
         const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
-        const float weight = expf_cr((-colorDiffSq / 3.0f) / denom);
+        const float weight = expf_glibc((-colorDiffSq / 3.0f) / denom);
         sumWeight += weight;
         weightedAvg += weight * image[j];
       }
@@ -1187,7 +1251,7 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
         const float e1 = (float)((int)ref.y - (int)sc.y) / 65535.0f;
         const float e2 = (float)((int)ref.z - (int)sc.z) / 65535.0f;
         const float weightedDiff = weight0 * (e0 * e0) + weight1 * (e1 * e1) + weight2 * (e2 * e2);
-        const float weight = expf_cr(-weightedDiff / sig2);
+        const float weight = expf_glibc(-weightedDiff / sig2);
         weightedSumPix += centre * weight;
         sumWeight += weight;
       }

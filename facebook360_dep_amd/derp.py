@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libderp_hip.so")
+LIB_PATH = os.environ.get("DERP_LIB") or os.path.join(_HERE, "libderp_hip.so")
 CAM_TYPES = {"FTHETA": 0, "RECTILINEAR": 1, "EQUISOLID": 2, "ORTHOGRAPHIC": 3}
 
 STAGES = ["fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject", "proj_bias", "brute_force",

@@ -279,3 +279,82 @@ def test_destination_subset(small):
         bad, rel = common.compare_disparity(g.download_disparity(0, d), ref[0][d], TOL)
         assert bad <= 2, (d, bad, rel)
     g.close()
+
+
+def test_sixteen_camera_rig_full_pyramid(built):
+    """BASELINE config 2's camera count (16 on a Fibonacci sphere, up to 15 sources per cost, which
+    exercises every branch of the nth_element restatement) at a size the oracle finishes in seconds."""
+    from facebook360_dep_amd import derp, synth
+
+    res = 128
+    rig = synth.make_rig(16, res)
+    sizes = synth.level_sizes(res, res, [128, 100, 80, 60, 50])
+    frame = synth.make_frame(rig, sizes)
+    cnt = {}
+    ref = common.oracle_pyramid(rig, sizes, frame, res, res, counters=cnt)
+    g = derp.Derp(rig["cameras"])
+    g.set_pyramid(sizes, res, res)
+    g.upload_frame(frame)
+    g.process_pyramid()
+    g.synchronize()  # also the coverage CHECK: a full sphere of cameras must not trip it
+    nbad = npx = 0
+    for level in ref:
+        for d in range(16):
+            bad, rel = common.compare_disparity(g.download_disparity(level, d), ref[level][d], TOL)
+            nbad += bad
+            npx += ref[level][d].size
+    print("16-camera rig: %d of %d pixels outside 1e-4" % (nbad, npx))
+    assert nbad <= 1e-4 * npx
+    got = g.counters()
+    assert got["n_cost"] == sum(c["n_cost"] for c in cnt.values())
+    assert abs(got["n_pair"] - sum(c["n_pair"] for c in cnt.values())) <= 1e-6 * got["n_pair"] + 4
+    g.close()
+
+
+def test_config2_full_size_properties(built):
+    """BASELINE config 2 at full size (16 cameras, 2048^2, 10 levels) — too big for the oracle, so
+    checked through size-independent properties: bit-identical reruns, NaN exactly outside the FOV
+    mask, disparities inside the search range (up to Lanczos ringing), agreement with the analytic
+    scene, and cost-evaluation counters equal to the closed form of the schedule."""
+    from facebook360_dep_amd import derp, synth
+
+    n, res, widths = synth.config("cfg2")
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    frame = synth.make_frame(rig, sizes, device="cuda")
+    g = derp.Derp(rig["cameras"])
+    g.set_pyramid(sizes, res, res)
+    g.upload_frame(frame)
+    g.process_pyramid()
+    g.synchronize()
+    first = [g.download_disparity(0, d) for d in (0, 7, 15)]
+    c1 = g.counters()
+    g.reset_counters()
+    g.process_pyramid()
+    g.synchronize()
+    c2 = g.counters()
+    assert c1 == c2
+    for i, d in enumerate((0, 7, 15)):
+        again = g.download_disparity(0, d)
+        assert _float_equal(first[i], again) == 0, "rerun differs"
+        fov = g.fov_mask(d, res, res)
+        assert np.array_equal(np.isnan(again), fov == 0)
+        v = again[fov == 1]
+        assert v.min() > 0 and v.max() < 2.0 * 1.05
+        truth = frame["truth"][d][fov == 1]
+        rel = np.abs(v - truth) / truth
+        print("cam %d: median rel err vs analytic scene %.4f, 90th pct %.4f" % (d, np.median(rel), np.percentile(rel, 90)))
+        assert np.median(rel) < 0.01 and np.percentile(rel, 90) < 0.1
+    # schedule: 150 costs/px at the coarsest level over fov interior; (1 + P) + 9 per gated pixel above
+    lvl = len(sizes) - 1
+    w, h = sizes[lvl]
+    interior = sum(int(g.fov_mask(d, w, h)[1:-1, 1:-1].sum()) for d in range(n))
+    assert g.profile_query("brute_force", lvl)["n_cost"] == 150 * interior
+    for level in (0, 3):
+        w, h = sizes[level]
+        interior = sum(int(g.fov_mask(d, w, h)[1:-1, 1:-1].sum()) for d in range(n))
+        pp = g.profile_query("ping_pong", level)["n_cost"]
+        rp = g.profile_query("random_proposals", level)["n_cost"]
+        assert pp <= 9 * interior and pp >= 0.9 * 9 * interior  # textured scene: nearly every pixel passes the variance gate
+        assert rp <= 3 * interior and rp % 3 == 0
+    g.close()
