@@ -102,8 +102,9 @@ __device__ __forceinline__ float bilerp_f(float p00, float p01, float p10, float
 // scalar bilerp<T = ushort>: float expression truncated to ushort
 __device__ __forceinline__ float bilerp_u16(float p00, float p01, float p10, float p11, float w00, float w01,
                                             float w10, float w11) {
+  // v lies in [0, 65535 * (1 + 2^-22)], so the reference's (ushort) conversion is a plain truncation
   const float v = w00 * p00 + w01 * p01 + w10 * p10 + w11 * p11;
-  return (float)(((unsigned int)v) & 0xffffu);
+  return __builtin_truncf(v);
 }
 
 struct PixCtx {

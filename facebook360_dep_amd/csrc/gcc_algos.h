@@ -24,9 +24,17 @@ struct SsdPair {
   float first, second;
 };
 
-// std::pair operator<
+// std::pair operator<: a.first < b.first || (!(b.first < a.first) && a.second < b.second).
+// SSD pairs are sums of squares: non-negative, never NaN, never -0 — for such floats the IEEE order
+// is the order of the bit patterns, so the lexicographic pair order is one unsigned 64-bit compare.
+DERP_HD unsigned long long pair_key(const SsdPair& a) {
+  unsigned int hi, lo;
+  __builtin_memcpy(&hi, &a.first, 4);
+  __builtin_memcpy(&lo, &a.second, 4);
+  return ((unsigned long long)hi << 32) | lo;
+}
 DERP_HD bool pair_less(const SsdPair& a, const SsdPair& b) {
-  return a.first < b.first || (!(b.first < a.first) && a.second < b.second);
+  return pair_key(a) < pair_key(b);
 }
 
 // A = accessor with get(i) / set(i, v); indices are absolute positions in the array.

@@ -285,6 +285,7 @@ def config(name):
     return {
         "cfg1": (4, 512, WIDTHS),
         "cfg2": (16, 2048, WIDTHS),
+        "cfg2s": (16, 512, WIDTHS),  # config 2's rig at a quarter of the resolution (profiling passes)
         "cfg4": (24, 4096, [4096] + WIDTHS),
         "tiny": (4, 96, [96, 64, 48]),
         "small": (6, 160, [160, 100, 64]),
