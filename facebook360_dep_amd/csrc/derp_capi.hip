@@ -503,15 +503,22 @@ int bilateral_radius(int level) {  // Derp.cpp:876-878
   return (int)std::max(std::ceil(5 * scale), float(1));
 }
 
+size_t bilateral_lds_bytes(int radius) {
+  const size_t t = (size_t)(16 + 2 * radius) * (16 + 2 * radius);
+  return t * 4 * sizeof(float) + ((t + 3) & ~(size_t)3);
+}
+
 int run_bilateral(derp_ctx* c) {
   const int L = c->cur;
   Span sp(c, ST_BILATERAL, L);
   const int W = c->LW[L], H = c->LH[L];
   const size_t n = (size_t)W * H;
   // weights passed (B, G, R) = (0.5, 1, 1) — Derp.cpp:893-896, Derp.h:44-48; sigma 0.005
-  hipLaunchKernelGGL(k_joint_bilateral_u16, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->disparity.as<float>(),
-                     c->pyrColor[L].as<ushort4>(), c->maskAnd.as<uint8_t>(), (const uint8_t*)nullptr, W, H,
-                     bilateral_radius(L), 0.005f, 0.5f, 1.0f, 1.0f, c->tmpF.as<float>(), n, n, c->dst2src.as<int>());
+  const int radius = bilateral_radius(L);
+  hipLaunchKernelGGL(k_joint_bilateral<true>, dim3((W + 15) / 16, (H + 15) / 16, c->D), dim3(256),
+                     bilateral_lds_bytes(radius), c->stream, c->disparity.as<float>(),
+                     (const void*)c->pyrColor[L].as<ushort4>(), c->maskAnd.as<uint8_t>(), W, H, radius, 0.005f, 0.5f,
+                     1.0f, 1.0f, c->tmpF.as<float>(), n, n, c->dst2src.as<int>());
   KCHECK(c);
   HIPCHK(c, hipMemcpyAsync(c->disparity.p, c->tmpF.p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
   return 0;
@@ -1233,8 +1240,8 @@ int derp_upsample_disparity(derp_ctx* c, int d, const float* disp, int w, int h,
 
 int derp_joint_bilateral_u16(derp_ctx* c, const float* image, const uint16_t* guide, const uint8_t* mask, int w, int h,
                              int radius, float sigma, float w0, float w1, float w2, float* out) {
-  if (!c || !image || !guide || !mask || !out) {
-    return fail(c, "bad arguments");
+  if (!c || !image || !guide || !mask || !out || radius < 0 || bilateral_lds_bytes(radius) > 64 * 1024) {
+    return fail(c, "bad arguments (radius must be in [0, 47])");
   }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)w * h;
@@ -1247,9 +1254,9 @@ int derp_joint_bilateral_u16(derp_ctx* c, const float* image, const uint16_t* gu
     (void)hipMemcpy(g3.p, guide, n * 6, hipMemcpyHostToDevice);
     (void)hipMemcpy(m.p, mask, n, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, g3.as<uint16_t>(), g4.as<ushort4>(), n);
-    hipLaunchKernelGGL(k_joint_bilateral_u16, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, im.as<float>(),
-                       g4.as<ushort4>(), m.as<uint8_t>(), (const uint8_t*)nullptr, w, h, radius, sigma, w0, w1, w2,
-                       res.as<float>(), n, n, (const int*)nullptr);
+    hipLaunchKernelGGL(k_joint_bilateral<true>, dim3((w + 15) / 16, (h + 15) / 16, 1), dim3(256),
+                       bilateral_lds_bytes(radius), c->stream, im.as<float>(), (const void*)g4.as<ushort4>(),
+                       m.as<uint8_t>(), w, h, radius, sigma, w0, w1, w2, res.as<float>(), n, n, (const int*)nullptr);
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, res.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
       rc = fail(c, "HIP error in derp_joint_bilateral_u16: %s", hipGetErrorString(hipGetLastError()));
     }
@@ -1262,8 +1269,8 @@ int derp_joint_bilateral_u16(derp_ctx* c, const float* image, const uint16_t* gu
 
 int derp_joint_bilateral_f32(derp_ctx* c, const float* image, const float* guide, const uint8_t* mask, int w, int h,
                              int radius, float sigma, float w0, float w1, float w2, float* out) {
-  if (!c || !image || !guide || !mask || !out) {
-    return fail(c, "bad arguments");
+  if (!c || !image || !guide || !mask || !out || radius < 0 || bilateral_lds_bytes(radius) > 64 * 1024) {
+    return fail(c, "bad arguments (radius must be in [0, 47])");
   }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)w * h;
@@ -1275,8 +1282,9 @@ int derp_joint_bilateral_f32(derp_ctx* c, const float* image, const float* guide
     (void)hipMemcpy(im.p, image, n * 4, hipMemcpyHostToDevice);
     (void)hipMemcpy(g.p, guide, n * 12, hipMemcpyHostToDevice);
     (void)hipMemcpy(m.p, mask, n, hipMemcpyHostToDevice);
-    hipLaunchKernelGGL(k_joint_bilateral_f32, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, im.as<float>(),
-                       g.as<float>(), m.as<uint8_t>(), w, h, radius, sigma, w0, w1, w2, res.as<float>());
+    hipLaunchKernelGGL(k_joint_bilateral<false>, dim3((w + 15) / 16, (h + 15) / 16, 1), dim3(256),
+                       bilateral_lds_bytes(radius), c->stream, im.as<float>(), (const void*)g.as<float>(),
+                       m.as<uint8_t>(), w, h, radius, sigma, w0, w1, w2, res.as<float>(), n, n, (const int*)nullptr);
     if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, res.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) {
       rc = fail(c, "HIP error in derp_joint_bilateral_f32: %s", hipGetErrorString(hipGetLastError()));
     }

@@ -922,7 +922,8 @@ __constant__ unsigned long long kExp2fTab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
-__device__ __forceinline__ float expf_glibc(float x) {
+// `tab` = kExp2fTab staged in LDS by the caller (a divergent __constant__ index would be a global load per call)
+__device__ __forceinline__ float expf_glibc(float x, const unsigned long long* tab) {
   const double InvLn2N = 0x1.71547652b82fep+0 * 32;
   const double C0 = 0x1.c6af84b912394p-5 / 32 / 32 / 32, C1 = 0x1.ebfce50fac4f3p-3 / 32 / 32,
                C2 = 0x1.62e42ff0c52d6p-1 / 32;
@@ -947,7 +948,7 @@ __device__ __forceinline__ float expf_glibc(float x) {
   const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
   kd -= SHIFT;
   const double r = __builtin_fma(InvLn2N, xd, -kd);
-  const unsigned long long t = kExp2fTab[ki & 31] + (ki << 47);
+  const unsigned long long t = tab[ki & 31] + (ki << 47);
   const double sc = __longlong_as_double((long long)t);
   const double z = __builtin_fma(C0, r, C1);
   const double r2 = r * r;
@@ -957,92 +958,87 @@ __device__ __forceinline__ float expf_glibc(float x) {
   return (float)y;
 }
 
-// generalizedJointBilateralFilter<float, Vec3w> — TemporalBilateralFilter.h:39-124.
-// guide = BGRX u16; mask = fov & fg; result written where `copyMask` (or everywhere if null).
-__global__ void k_joint_bilateral_u16(const float* __restrict__ image, const ushort4* __restrict__ guide,
-                                      const uint8_t* __restrict__ mask, const uint8_t* __restrict__ copyMask, int W,
-                                      int H, int radius, float sigma, float weight0, float weight1, float weight2,
-                                      float* __restrict__ out, size_t planeStride, size_t guideStride,
-                                      const int* __restrict__ guideIndex) {
-  const int p = blockIdx.z;
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
-  if (x >= W || y >= H) {
-    return;
+// generalizedJointBilateralFilter — TemporalBilateralFilter.h:39-124. One 16x16 pixel tile per
+// block; the (16+2r)^2 neighbourhood (guide colour, mask, image value, already clamped to the image
+// edge like the reference's sample coordinates) is staged once in LDS, so the (2r+1)^2 taps of each
+// pixel are LDS reads instead of 3 global loads each. Tap order (v outer, u inner), the masked-tap
+// skip and the float accumulation are the reference's.
+//   GUIDE_U16 = true : guide is BGRX u16 (TGuide = Vec3w, factor 1/65535)   — Derp.cpp:875-902
+//   GUIDE_U16 = false: guide is 3 x f32 (TGuide = Vec3f, factor 1)          — UpsampleDisparity.cpp:109-128
+template <bool GUIDE_U16>
+__global__ void __launch_bounds__(256)
+    k_joint_bilateral(const float* __restrict__ image, const void* __restrict__ guideV,
+                      const uint8_t* __restrict__ mask, int W, int H, int radius, float sigma, float weight0,
+                      float weight1, float weight2, float* __restrict__ out, size_t planeStride, size_t guideStride,
+                      const int* __restrict__ guideIndex) {
+  extern __shared__ float ldsTile[];
+  __shared__ unsigned long long expTab[32];
+  if (threadIdx.x < 32) {
+    expTab[threadIdx.x] = kExp2fTab[threadIdx.x];
   }
-  const size_t idx = (size_t)y * W + x;
+  const int p = blockIdx.z;
+  const int T = 16 + 2 * radius;
+  const int n = T * T;
+  float* tImg = ldsTile;                  // [n]
+  float* tG0 = ldsTile + n;               // [n] x 3 guide channels (already scaled by the factor)
+  float* tG1 = ldsTile + 2 * n;
+  float* tG2 = ldsTile + 3 * n;
+  uint8_t* tMask = reinterpret_cast<uint8_t*>(ldsTile + 4 * n);
   const float* img = image + (size_t)p * planeStride;
   const uint8_t* m = mask + (size_t)p * planeStride;
-  const ushort4* g = guide + (size_t)(guideIndex ? guideIndex[p] : p) * guideStride;
-  float result = img[idx];
-  if (m[idx]) {
-    const ushort4 gc = g[idx];
-    const float factor = 1 / 65535.0f;
-    const float g0 = gc.x * factor, g1 = gc.y * factor, g2 = gc.z * factor;
-    const float denom = 2.0f * (sigma * sigma);
-    float sumWeight = 0.f, weightedAvg = 0.f;
-    for (int v = -radius; v <= radius; ++v) {
-      const int sy = min(max(y + v, 0), H - 1);
-      for (int u = -radius; u <= radius; ++u) {
-        const int sx = min(max(x + u, 0), W - 1);
-        const size_t j = (size_t)sy * W + sx;
-        if (!m[j]) {
-          continue;
-        }
-        const ushort4 nb = g[j];
-        const float d0 = g0 - nb.x * factor, d1 = g1 - nb.y * factor, d2 = g2 - nb.z * factor;
-        const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
-        const float weight = expf_glibc((-colorDiffSq / 3.0f) / denom);
-        sumWeight += weight;
-        weightedAvg += weight * img[j];
-      }
-    }
-    if (sumWeight != 0.0f) {
-      result = weightedAvg / sumWeight;
+  const size_t gplane = (size_t)(guideIndex ? guideIndex[p] : p) * guideStride;
+  const int x0 = blockIdx.x * 16 - radius, y0 = blockIdx.y * 16 - radius;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ty = i / T, tx = i - ty * T;
+    const int sx = min(max(x0 + tx, 0), W - 1), sy = min(max(y0 + ty, 0), H - 1);
+    const size_t j = (size_t)sy * W + sx;
+    tImg[i] = img[j];
+    tMask[i] = m[j];
+    if (GUIDE_U16) {
+      const ushort4 g = reinterpret_cast<const ushort4*>(guideV)[gplane + j];
+      const float factor = 1 / 65535.0f;
+      tG0[i] = g.x * factor;
+      tG1[i] = g.y * factor;
+      tG2[i] = g.z * factor;
+    } else {
+      const float* g = reinterpret_cast<const float*>(guideV) + (gplane + j) * 3;
+      const float factor = 1 / 1.0f;
+      tG0[i] = g[0] * factor;
+      tG1[i] = g[1] * factor;
+      tG2[i] = g[2] * factor;
     }
   }
-  if (!copyMask || copyMask[(size_t)(guideIndex ? guideIndex[p] : p) * guideStride + idx]) {
-    out[(size_t)p * planeStride + idx] = result;
-  } else {
-    out[(size_t)p * planeStride + idx] = img[idx];
-  }
-}
-
-// generalizedJointBilateralFilter<float, Vec3f> (UpsampleDisparity.cpp:109-128), guide = 3 floats
-__global__ void k_joint_bilateral_f32(const float* __restrict__ image, const float* __restrict__ guide,
-                                      const uint8_t* __restrict__ mask, int W, int H, int radius, float sigma,
-                                      float weight0, float weight1, float weight2, float* __restrict__ out) {
-  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  __syncthreads();
+  const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int x = blockIdx.x * 16 + lx, y = blockIdx.y * 16 + ly;
   if (x >= W || y >= H) {
     return;
   }
-  const size_t idx = (size_t)y * W + x;
-  float result = image[idx];
-  if (mask[idx]) {
-    const float factor = 1 / 1.0f;
-    const float g0 = guide[3 * idx] * factor, g1 = guide[3 * idx + 1] * factor, g2 = guide[3 * idx + 2] * factor;
+  const int c = (ly + radius) * T + lx + radius;
+  float result = tImg[c];
+  if (tMask[c]) {
+    const float g0 = tG0[c], g1 = tG1[c], g2 = tG2[c];
     const float denom = 2.0f * (sigma * sigma);
     float sumWeight = 0.f, weightedAvg = 0.f;
     for (int v = -radius; v <= radius; ++v) {
-      const int sy = min(max(y + v, 0), H - 1);
+      const int row = c + v * T;
       for (int u = -radius; u <= radius; ++u) {
-        const int sx = min(max(x + u, 0), W - 1);
-        const size_t j = (size_t)sy * W + sx;
-        if (!mask[j]) {
+        const int j = row + u;
+        if (!tMask[j]) {
           continue;
         }
-        const float d0 = g0 - guide[3 * j] * factor, d1 = g1 - guide[3 * j + 1] * factor,
-                    d2 = g2 - guide[3 * j + 2] * factor;
+        const float d0 = g0 - tG0[j], d1 = g1 - tG1[j], d2 = g2 - tG2[j];
         const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
-        const float weight = expf_glibc((-colorDiffSq / 3.0f) / denom);
+        const float weight = expf_glibc((-colorDiffSq / 3.0f) / denom, expTab);
         sumWeight += weight;
-        weightedAvg += weight * image[j];
+        weightedAvg += weight * tImg[j];
       }
     }
     if (sumWeight != 0.0f) {
       result = weightedAvg / sumWeight;
     }
   }
-  out[idx] = result;
+  out[(size_t)p * planeStride + (size_t)y * W + x] = result;
 }
 
 // maskedMedianBlur radius 1 — CvUtil.h:336-385; optional fused maskFov (Derp.cpp:940-951)
@@ -1225,6 +1221,14 @@ struct TemporalFrames {
 };
 __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, float sigma, int radius, float weight0,
                            float weight1, float weight2, float* __restrict__ out) {
+  __shared__ unsigned long long expTab[32];
+  {
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < 32) {
+      expTab[t] = kExp2fTab[t];
+    }
+  }
+  __syncthreads();
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= W || y >= H) {
     return;
@@ -1252,7 +1256,7 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
         const float e1 = (float)((int)ref.y - (int)sc.y) / 65535.0f;
         const float e2 = (float)((int)ref.z - (int)sc.z) / 65535.0f;
         const float weightedDiff = weight0 * (e0 * e0) + weight1 * (e1 * e1) + weight2 * (e2 * e2);
-        const float weight = expf_glibc(-weightedDiff / sig2);
+        const float weight = expf_glibc(-weightedDiff / sig2, expTab);
         weightedSumPix += centre * weight;
         sumWeight += weight;
       }
