@@ -225,8 +225,10 @@ def main():
         "dtype": "f32 photometry + f64 geometry over u16 texels",
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE config 2: %d-camera %dx%d synthetic rig, single frame, full %d-level pyramid"
-                         % (n_cams, res, res, n_levels)) if not temporal else
+            "workload": ("%s: %d-camera %dx%d synthetic rig, single frame, full %d-level pyramid"
+                         % ({"cfg1": "BASELINE config 1", "cfg2": "BASELINE config 2", "cfg4": "BASELINE config 4"}.get(
+                             args.config, "developer config " + args.config), n_cams, res, res, n_levels))
+                        if not temporal else
                         ("BASELINE config 3 shape: %d-camera %dx%d rig, %d-frame sequence one frame per GPU, "
                          "per-level temporal filter with RCCL all_gather of the level disparity" %
                          (n_cams, res, res, world)),

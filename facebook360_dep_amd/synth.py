@@ -115,7 +115,8 @@ def pixel_rays(cam, w, h, device=None):
     s = torch.where(norm > 0, torch.sin(theta) / norm.clamp_min(1e-300), torch.zeros_like(norm))
     unit = torch.stack([s * sx, s * sy, -torch.cos(theta)], -1)
     R = torch.tensor([cam["right"], cam["up"], [-v for v in cam["forward"]]], dtype=torch.float64, device=dev)
-    return unit @ R  # R^T * unit
+    # R^T * unit, written element-wise (BLAS gemv/gemm rejects the 16.8 M-row case of config 4)
+    return unit[..., 0:1] * R[0] + unit[..., 1:2] * R[1] + unit[..., 2:3] * R[2]
 
 
 # ---------------------------------------------------------------- scene
@@ -178,7 +179,7 @@ def intersect(origin, d, shift):
     import torch
 
     o = torch.tensor([origin[i] - shift[i] for i in range(3)], dtype=torch.float64, device=d.device)
-    b = d @ o
+    b = (d * o).sum(-1)
     c = float(o @ o) - SPHERE_R**2
     tb = -b + torch.sqrt((b * b - c).clamp_min(0.0))
     t = tb.clone()
@@ -186,7 +187,7 @@ def intersect(origin, d, shift):
     for n, cc, centre, half in PLANES:
         n = torch.tensor(n, dtype=torch.float64, device=d.device)
         centre = torch.tensor(centre, dtype=torch.float64, device=d.device)
-        denom = d @ n
+        denom = (d * n).sum(-1)
         denom = torch.where(denom.abs() > 1e-9, denom, torch.full_like(denom, 1e-9))
         tp = (cc - float(o @ n)) / denom
         hit = o + tp[..., None] * d
