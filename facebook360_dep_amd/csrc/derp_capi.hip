@@ -421,10 +421,12 @@ int build_color_tables(derp_ctx* c, int dst0, int nd) {
   return 0;
 }
 
+// number of cost-kernel blocks covering a W x H image (16x16 super-tiles of four 8x8 wave tiles)
 int tiles_of(int W, int H, int& tilesX) {
   tilesX = (W + 15) / 16;
-  return tilesX * ((H + 15) / 16);
+  return tilesX * ((H + 15) / 16) * (256 / DERP_COST_BLOCK);
 }
+constexpr size_t kCostLdsPerSrc = (size_t)DERP_COST_BLOCK * sizeof(SsdPair);
 int round8(int n) {
   return (n + 7) / 8 * 8;
 }
@@ -441,8 +443,8 @@ int run_brute_force(derp_ctx* c, int dst0, int nd) {
   ALLOC(c, c->bruteConf, (size_t)nd * kNumDepths * n * sizeof(float));
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
-  hipLaunchKernelGGL(k_brute_costs, dim3(tiles, kNumDepths, nd), dim3(256), lds, c->stream, V,
+  const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
+  hipLaunchKernelGGL(k_brute_costs, dim3(tiles, kNumDepths, nd), dim3(DERP_COST_BLOCK), lds, c->stream, V,
                      c->bruteCost.as<float>(), c->bruteConf.as<float>(), tilesX, tiles);
   KCHECK(c);
   hipLaunchKernelGGL(k_brute_select, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->bruteCost.as<float>(),
@@ -466,8 +468,8 @@ int run_random_proposals(derp_ctx* c, int dst0, int nd) {
   }
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
-  hipLaunchKernelGGL(k_random_proposals, dim3(round8(tiles), nd), dim3(256), lds, c->stream, V, c->rank.as<int>(),
+  const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
+  hipLaunchKernelGGL(k_random_proposals, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->rank.as<int>(),
                      tilesX, tiles);
   KCHECK(c);
   return 0;
@@ -484,9 +486,9 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   HIPCHK(c, hipMemsetAsync(c->changed.as<uint8_t>() + (size_t)dst0 * n, 1, n * nd, c->stream));
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
+  const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
   for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
-    hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(256), lds, c->stream, V, c->changed.as<uint8_t>(),
+    hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->changed.as<uint8_t>(),
                        c->dispRes.as<float>(), c->costRes.as<float>(), tilesX, tiles);
     KCHECK(c);
     hipLaunchKernelGGL(k_ping_pong_commit, dim3(flat_grid(n * nd)), dim3(256), 0, c->stream,
@@ -1091,8 +1093,8 @@ int derp_cost_map(derp_ctx* c, int d, const float* disp, float* cost, float* con
   LevelView V = make_view(c, ST_PINGPONG, 0, c->D);
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = 256 * (size_t)(c->S) * sizeof(SsdPair);
-  hipLaunchKernelGGL(k_cost_map, dim3(tiles), dim3(256), lds, c->stream, V, d, c->staging.as<float>(),
+  const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
+  hipLaunchKernelGGL(k_cost_map, dim3(tiles), dim3(DERP_COST_BLOCK), lds, c->stream, V, d, c->staging.as<float>(),
                      c->stagingB.as<float>(), c->stagingB.as<float>() + n, tilesX);
   KCHECK(c);
   HIPCHK(c, hipStreamSynchronize(c->stream));

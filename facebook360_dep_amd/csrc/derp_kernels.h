@@ -29,6 +29,9 @@ namespace derp {
 #ifndef DERP_COST_MIN_WAVES
 #define DERP_COST_MIN_WAVES 2
 #endif
+#ifndef DERP_COST_BLOCK
+#define DERP_COST_BLOCK 64
+#endif
 static constexpr int kPadW = 1;   // ring of projWarp
 static constexpr int kPadC = 2;   // ring of projColor / projBias
 static constexpr int kMaxSrc = 32;
@@ -84,12 +87,17 @@ __device__ __forceinline__ int xcd_swizzle(int b, int n) {
   return t;
 }
 
-// pixel of a 16x16 tile handled by this thread: waves own 8x8 sub-tiles
-__device__ __forceinline__ void tile_pixel(int tile, int tilesX, int& x, int& y) {
-  const int tx = tile % tilesX, ty = tile / tilesX;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  x = tx * 16 + (wave & 1) * 8 + (lane & 7);
-  y = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
+// Pixel handled by this thread. A wave owns an 8x8 pixel tile; four consecutive waves form a 16x16
+// super-tile (raster order over super-tiles). `item` numbers the blocks of the launch; a block holds
+// blockDim.x / 64 consecutive waves. Cost kernels run ONE wave per block (DERP_COST_BLOCK = 64): the
+// waves of a pixel tile finish at very different times, and a single-wave block frees its slot at once.
+__device__ __forceinline__ void tile_pixel(int item, int tilesX, int& x, int& y) {
+  const int lane = threadIdx.x & 63;
+  const int gw = item * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
+  const int super = gw >> 2, quad = gw & 3;
+  const int tx = super % tilesX, ty = super / tilesX;
+  x = tx * 16 + (quad & 1) * 8 + (lane & 7);
+  y = ty * 16 + (quad >> 1) * 8 + (lane >> 3);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -624,7 +632,7 @@ __device__ __forceinline__ float probe_disparity(int i, float minD, float maxD) 
   return (float)(fraction * (double)minD + (1 - fraction) * (double)maxD);
 }
 
-__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     k_brute_costs(LevelView V, float* __restrict__ costs, float* __restrict__ confs, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
   const int i = blockIdx.y;   // disparity index
@@ -760,7 +768,7 @@ __global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     k_random_proposals(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
   const int dl = blockIdx.y;
@@ -815,7 +823,7 @@ __global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
 // ----------------------------------------------------------------------------------------
 __constant__ int kCandidates[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-2, -2}, {2, -2}, {-2, 2}, {2, 2}};
 
-__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     k_ping_pong(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
                 float* __restrict__ costRes, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
@@ -882,7 +890,7 @@ __global__ void k_ping_pong_commit(float* __restrict__ disp, float* __restrict__
 }
 
 // cost map of a caller-supplied disparity image (test hook over compute_cost)
-__global__ void __launch_bounds__(256, DERP_COST_MIN_WAVES)
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     k_cost_map(LevelView V, int d, const float* __restrict__ dispIn, float* __restrict__ costOut,
                float* __restrict__ confOut, int tilesX) {
   extern __shared__ SsdPair ldsPairs[];
