@@ -260,6 +260,19 @@ int main(int argc, char** argv) {
           }
           write_disparity_png(levelDir((fs::path(outputRoot) / "cost").string(), level) / rigDst[d].id / (frameName + ".png"),
                               cost.data(), W[level], H[level]);
+          for (auto& v : conf) {
+            v *= 255.0f * 100.0f / 65535.0f * 257.0f;  // kScaleConfidencePlot
+          }
+          write_disparity_png(levelDir((fs::path(outputRoot) / "confidence").string(), level) / rigDst[d].id / (frameName + ".png"),
+                              conf.data(), W[level], H[level]);
+          std::vector<uint8_t> mm(disp.size());
+          DERP_OK(ctx, derp_download_mismatch_mask(ctx, d, mm.data()));
+          std::vector<uint16_t> mpx(mm.size());
+          for (size_t i = 0; i < mm.size(); ++i) {
+            mpx[i] = mm[i] ? 255 : 0;
+          }
+          write_png(levelDir((fs::path(outputRoot) / "mismatches").string(), level) / rigDst[d].id / (frameName + ".png"),
+                    mpx.data(), W[level], H[level], 1, 8);
         }
       }
       LOG_INFO(fmt("-- Elapsed time: %.3fs wall (frame %s, level %d)", frameTimer.s(), frameName.c_str(), level));

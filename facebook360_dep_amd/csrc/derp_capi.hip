@@ -31,6 +31,7 @@ enum Stage {
   ST_BRUTE,
   ST_RANDOM,
   ST_PINGPONG,
+  ST_MISMATCH,
   ST_BILATERAL,
   ST_MEDIAN,
   ST_MASKFOV,
@@ -38,7 +39,7 @@ enum Stage {
 };
 const char* kStageNames[ST_COUNT] = {"fov_mask",  "variance",    "own_bias",         "upsample",  "proj_warp",
                                      "reproject", "proj_bias",   "brute_force",      "random_proposals",
-                                     "ping_pong", "bilateral",   "median",           "mask_fov"};
+                                     "ping_pong", "mismatches",  "bilateral",        "median",    "mask_fov"};
 constexpr int kMaxLevels = 24;
 
 struct DevBuf {
@@ -103,7 +104,7 @@ struct derp_ctx {
   // working level
   int cur = -1;
   int DB = 0;  // dst batch that fits the table budget
-  DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank;
+  DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask;
   DevBuf projWarp, projColor, projBias, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
   int warpCachedLevel = -1;
   bool tablesValid = false;
@@ -500,6 +501,30 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   return 0;
 }
 
+// handleDisparityMismatches (Derp.cpp:722-748): after every destination finished ping-pong
+int run_mismatches(derp_ctx* c) {
+  const int L = c->cur;
+  if (L > c->opt.mismatches_start_level || L == c->numLevels - 1) {
+    return 0;
+  }
+  if (c->D != c->S) {
+    return fail(c, "Check failed: rigDst.size() == rigSrc.size()  Mismatches only valid when considering all cameras");
+  }
+  for (int d = 0; d < c->D; ++d) {
+    if (c->dst2srcH[d] != d) {
+      return fail(c, "mismatch handling needs destinations in rig order (dst %d maps to src %d)", d, c->dst2srcH[d]);
+    }
+  }
+  Span sp(c, ST_MISMATCH, L);
+  LevelView V = make_view(c, ST_MISMATCH, 0, c->D);
+  const size_t n = (size_t)V.W * V.H;
+  hipLaunchKernelGGL(k_mismatch, dim3((V.W + 15) / 16, (V.H + 15) / 16, c->D), dim3(256), 256 * sizeof(float) * c->S,
+                     c->stream, V, c->dispRes.as<float>(), c->mismatchMask.as<uint8_t>());
+  KCHECK(c);
+  HIPCHK(c, hipMemcpyAsync(c->disparity.p, c->dispRes.p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+
 int bilateral_radius(int level) {  // Derp.cpp:876-878
   const float scale = std::pow(0.9f, level);
   return (int)std::max(std::ceil(5 * scale), float(1));
@@ -591,6 +616,7 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   // fresh PyramidLevel: disparity / cost / confidence start at 0 (PyramidLevel.h:209-221)
   HIPCHK(c, hipMemsetAsync(c->cost.p, 0, n * c->D * sizeof(float), c->stream));
   HIPCHK(c, hipMemsetAsync(c->confidence.p, 0, n * c->D * sizeof(float), c->stream));
+  HIPCHK(c, hipMemsetAsync(c->mismatchMask.p, 0, n * c->D, c->stream));
   if (level < c->numLevels - 1 && !c->haveDisp[level + 1] && !buildAllTables) {
     return fail(c, "Missing disparity of level %d needed to start level %d", level + 1, level);
   }
@@ -675,6 +701,7 @@ int process_level(derp_ctx* c, int level) {
     TRY(run_random_proposals(c, d0, nd));
     TRY(run_ping_pong(c, d0, nd));
   }
+  TRY(run_mismatches(c));
   if (c->opt.do_bilateral_filter) {
     TRY(run_bilateral(c));
   }
@@ -816,7 +843,7 @@ void derp_destroy(derp_ctx* c) {
     }
   }
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
-                    &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank,
+                    &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask,
                     &c->projWarp, &c->projColor, &c->projBias, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
@@ -837,9 +864,6 @@ const char* derp_last_error(const derp_ctx* c) {
 int derp_set_options(derp_ctx* c, const derp_options* o) {
   if (!c || !o) {
     return 1;
-  }
-  if (o->mismatches_start_level != -1) {
-    return fail(c, "mismatches_start_level=%d: mismatch handling is not implemented (only -1)", o->mismatches_start_level);
   }
   if (o->random_proposals < 0) {
     return fail(c, "Check failed: random_proposals >= 0");
@@ -890,6 +914,7 @@ int derp_set_pyramid(derp_ctx* c, int num_levels, const int* widths, const int* 
     ALLOC(c, *b, nmax * c->D * sizeof(float));
   }
   ALLOC(c, c->changed, nmax * c->D);
+  ALLOC(c, c->mismatchMask, nmax * c->D);
   c->cur = -1;
   c->warpCachedLevel = -1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1043,6 +1068,10 @@ int derp_stage_ping_pong(derp_ctx* c) {
   TRY(need_current(c, true));
   return run_ping_pong(c, 0, c->D);
 }
+int derp_stage_mismatches(derp_ctx* c) {
+  TRY(need_current(c, false));
+  return run_mismatches(c);
+}
 int derp_stage_bilateral_filter(derp_ctx* c) {
   TRY(need_current(c, false));
   return run_bilateral(c);
@@ -1152,6 +1181,39 @@ int derp_debug_download(derp_ctx* c, int d, int s, int which, void* out) {
 }
 
 // ---- sibling binaries' kernels, host-pointer convenience forms ----
+int derp_layer_disparities(derp_ctx* c, const float* foreground, const float* background, size_t n, uint8_t* out) {
+  if (!c || !foreground || !background || !out) {
+    return fail(c, "bad arguments");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf f, b, o;
+  int rc = 0;
+  if (f.ensure(n * 4) || b.ensure(n * 4) || o.ensure(n)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(f.p, foreground, n * 4, hipMemcpyHostToDevice);
+    (void)hipMemcpy(b.p, background, n * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_layer_disparities, dim3(flat_grid(n)), dim3(256), 0, c->stream, f.as<float>(), b.as<float>(), n,
+                       o.as<uint8_t>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(out, o.p, n, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_layer_disparities: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* x : {&f, &b, &o}) {
+    x->release();
+  }
+  return rc;
+}
+int derp_download_mismatch_mask(derp_ctx* c, int d, uint8_t* out) {
+  TRY(need_current(c, false));
+  if (d < 0 || d >= c->D || !out) {
+    return fail(c, "bad destination index / null output");
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = npx(c, c->cur);
+  HIPCHK(c, hipMemcpy(out, c->mismatchMask.as<uint8_t>() + (size_t)d * n, n, hipMemcpyDeviceToHost));
+  return 0;
+}
 int derp_fov_mask(derp_ctx* c, int d, int w, int h, uint8_t* out) {
   if (!c || !out || d < 0 || d >= c->D || w <= 0 || h <= 0) {
     return fail(c, "bad arguments");

@@ -889,6 +889,106 @@ __global__ void k_ping_pong_commit(float* __restrict__ disp, float* __restrict__
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// handleDisparityMismatches — Derp.cpp:553-748 (off unless level <= --mismatches_start_level).
+// Jacobi over destinations: reads every camera's disparity, writes newDisp + the mismatch mask.
+// The reference indexes dstDisparity(srcIdx), i.e. requires dst i == src i (checked on the host).
+// ----------------------------------------------------------------------------------------
+__device__ __forceinline__ float clamp_fetch(const float* img, int x, int y, int W, int H) {
+  return img[(size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1)];
+}
+
+__global__ void __launch_bounds__(256)
+    k_mismatch(LevelView V, float* __restrict__ newDisp, uint8_t* __restrict__ mismatchMask) {
+  extern __shared__ float ldsMis[];
+  const int d = blockIdx.z;
+  const int x = blockIdx.x * 16 + (threadIdx.x & 15), y = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (x >= V.W || y >= V.H) {
+    return;
+  }
+  const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+  if (!V.fovMask[(size_t)d * n + idx]) {
+    newDisp[(size_t)d * n + idx] = __builtin_nanf("");  // dstDispNew starts as NaN and is never written here
+    return;
+  }
+  float* mis = ldsMis + threadIdx.x;  // mis[i * 256]
+  const int own = V.dst2src[d];
+  const float curr = V.disparity[(size_t)d * n + idx];
+  int nMatch = 0, nMis = 0;
+  if (V.srcFg[(size_t)own * n + idx]) {  // getSrcMismatches
+    const Cam& cd = V.camsDst[d];
+    const D3 dir = rig_direction(cd, (x + 0.5) / (double)V.W, (y + 0.5) / (double)V.H, cd.principal[0], cd.principal[1],
+                                 cd.focal[0], cd.focal[1]);
+    const double depth = (double)(1.0f / curr);
+    const D3 pWorld = {cd.pos[0] + dir.x * depth, cd.pos[1] + dir.y * depth, cd.pos[2] + dir.z * depth};
+    const float dMin = (1.0f - 0.1f) * curr, dMax = (1.0f + 0.1f) * curr;
+    for (int s = 0; s < V.S; ++s) {
+      if (s == own) {
+        continue;
+      }
+      const Cam& cs = V.camsSrc[s];
+      D2 pn;
+      if (!sees(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1], 1.0, 1.0, pn)) {
+        continue;
+      }
+      const float sx = (float)(pn.x * (double)V.W), sy = (float)(pn.y * (double)V.H);
+      const float xf = roundf(sx), yf = roundf(sy);
+      const int xi = (int)xf, yi = (int)yf;
+      const float xw = sx - xf + 0.5f, yw = sy - yf + 0.5f;
+      const float* img = V.disparity + (size_t)s * n;  // dstDisparity(srcIdx)
+      const float dSrc = bilerp_f(clamp_fetch(img, xi - 1, yi - 1, V.W, V.H), clamp_fetch(img, xi, yi - 1, V.W, V.H),
+                                  clamp_fetch(img, xi - 1, yi, V.W, V.H), clamp_fetch(img, xi, yi, V.W, V.H),
+                                  (1 - xw) * (1 - yw), xw * (1 - yw), (1 - xw) * yw, xw * yw);
+      if (dMin <= dSrc && dSrc <= dMax) {
+        ++nMatch;
+      } else {
+        mis[(nMis++) * 256] = dSrc;
+      }
+    }
+  }
+  // updateDstDisparityAndMismatchMask
+  bool mask = false;
+  float dispNew = curr;
+  if (nMatch + nMis != 0) {
+    const float var = V.srcVar[(size_t)own * n + idx];
+    if (!(nMatch >= 1 || V.varHighThresh < var || var < V.varNoiseFloor)) {
+      mask = true;
+      for (int i = 1; i < nMis; ++i) {  // std::sort: ascending values
+        const float v = mis[i * 256];
+        int k = i;
+        while (k > 0 && mis[(k - 1) * 256] > v) {
+          mis[k * 256] = mis[(k - 1) * 256];
+          --k;
+        }
+        mis[k * 256] = v;
+      }
+      int closer = 0;
+      for (; closer < nMis; ++closer) {
+        if (mis[closer * 256] >= curr) {
+          break;
+        }
+      }
+      const float m = mis[(closer / 2) * 256];
+      dispNew = (m < curr) ? m : curr;  // std::min(dispCurr, dispMismatches[median])
+    }
+  }
+  mismatchMask[(size_t)d * n + idx] = mask;
+  newDisp[(size_t)d * n + idx] = dispNew;
+}
+
+// LayerDisparities.cpp:45-55: mask = fg > 0; layer = fg*mask + bg*(1-mask); cv::imwrite(layer * 255) -> CV_8U
+__global__ void k_layer_disparities(const float* __restrict__ fg, const float* __restrict__ bg, size_t n,
+                                    uint8_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float m = fg[i] > 0.0f ? 1.0f : 0.0f;
+    const float layer = fg[i] * m + bg[i] * (1 - m);
+    const int r = cv_round(layer * 255.0f);
+    out[i] = (uint8_t)min(max(r, 0), 255);
+  }
+}
+
 // cost map of a caller-supplied disparity image (test hook over compute_cost)
 __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     k_cost_map(LevelView V, int d, const float* __restrict__ dispIn, float* __restrict__ costOut,

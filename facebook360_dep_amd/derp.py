@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DERP_LIB") or os.path.join(_HERE, "libderp_hip.so")
 CAM_TYPES = {"FTHETA": 0, "RECTILINEAR": 1, "EQUISOLID": 2, "ORTHOGRAPHIC": 3}
 
 STAGES = ["fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject", "proj_bias", "brute_force",
-          "random_proposals", "ping_pong", "bilateral", "median", "mask_fov"]
+          "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov"]
 
 
 class CameraDesc(C.Structure):
@@ -40,9 +40,9 @@ EXPORTS = [
     "derp_upload_color", "derp_upload_foreground_mask", "derp_upload_background_disparity", "derp_upload_disparity",
     "derp_process_level", "derp_process_pyramid", "derp_synchronize", "derp_download_disparity", "derp_download_cost",
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
-    "derp_stage_ping_pong", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
+    "derp_stage_ping_pong", "derp_stage_mismatches", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
-    "derp_fov_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
+    "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query",
     "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
@@ -230,7 +230,7 @@ class Derp:
         fn = {
             "reproject_colors": "derp_stage_reproject_colors", "brute_force": "derp_stage_brute_force",
             "random_proposals": "derp_stage_random_proposals", "ping_pong": "derp_stage_ping_pong",
-            "bilateral": "derp_stage_bilateral_filter", "median": "derp_stage_median_filter",
+            "mismatches": "derp_stage_mismatches", "bilateral": "derp_stage_bilateral_filter", "median": "derp_stage_median_filter",
             "mask_fov": "derp_stage_mask_fov", "end": "derp_level_end",
         }[name]
         self._ck(getattr(lib(), fn)(self.h))
@@ -260,7 +260,19 @@ class Derp:
         self._ck(lib().derp_debug_download(self.h, d, s, spec[0], _p(out)))
         return out
 
+    def mismatch_mask(self, d):
+        out = np.zeros(self._shape(self._cur), dtype=np.uint8)
+        self._ck(lib().derp_download_mismatch_mask(self.h, d, _p(out)))
+        return out
+
     # ---- sibling kernels
+    def layer_disparities(self, fg, bg):
+        fg = np.ascontiguousarray(fg, dtype=np.float32)
+        bg = np.ascontiguousarray(bg, dtype=np.float32)
+        out = np.zeros(fg.shape, dtype=np.uint8)
+        self._ck(lib().derp_layer_disparities(self.h, _p(fg), _p(bg), C.c_size_t(fg.size), _p(out)))
+        return out
+
     def fov_mask(self, d, w, h):
         out = np.zeros((h, w), dtype=np.uint8)
         self._ck(lib().derp_fov_mask(self.h, d, w, h, _p(out)))

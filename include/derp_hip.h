@@ -59,7 +59,7 @@ typedef struct {
   float var_high_thresh;        /* --var_high_thresh        1e-3  */
   int32_t random_proposals;     /* --random_proposals       2     */
   int32_t ping_pong_iterations; /* --ping_pong_iterations   1     */
-  int32_t mismatches_start_level; /* --mismatches_start_level -1 (only -1 supported) */
+  int32_t mismatches_start_level; /* --mismatches_start_level -1 (-1 = no mismatch handling) */
   int32_t do_bilateral_filter;  /* --do_bilateral_filter    1     */
   int32_t do_median_filter;     /* --do_median_filter       1     */
   int32_t use_foreground_masks; /* --use_foreground_masks   0     */
@@ -112,6 +112,7 @@ int derp_stage_reproject_colors(derp_ctx* ctx);     /* reprojectColors,        D
 int derp_stage_brute_force(derp_ctx* ctx);          /* preprocessLevel,        Derp.cpp:826-842  */
 int derp_stage_random_proposals(derp_ctx* ctx);     /* randomProposals,        Derp.cpp:844-873  */
 int derp_stage_ping_pong(derp_ctx* ctx);            /* pingPongPropagation,    Derp.cpp:540-551  */
+int derp_stage_mismatches(derp_ctx* ctx);           /* handleDisparityMismatches, Derp.cpp:722-748 */
 int derp_stage_bilateral_filter(derp_ctx* ctx);     /* bilateralFilter,        Derp.cpp:875-902  */
 int derp_stage_median_filter(derp_ctx* ctx);        /* medianFilter,           Derp.cpp:904-920  */
 int derp_stage_mask_fov(derp_ctx* ctx);             /* maskFov,                Derp.cpp:940-951  */
@@ -125,7 +126,13 @@ int derp_cost_map(derp_ctx* ctx, int dst, const float* disp, float* cost, float*
  * (u16x3), 4 variance of src (float), 5 fov mask of dst (u8; src ignored) */
 int derp_debug_download(derp_ctx* ctx, int dst, int src, int which, void* out);
 
+/* mismatch mask of the level processed last (dstMismatchedDisparityMask, PyramidLevel.h:332-338) */
+int derp_download_mismatch_mask(derp_ctx* ctx, int dst, uint8_t* out);
+
 /* ---- the sibling binaries' kernels ------------------------------------------------------- */
+/* layerDisparities (LayerDisparities.cpp:45-55): fg over bg where fg > 0, x255, saturate to 8 bit */
+int derp_layer_disparities(derp_ctx* ctx, const float* foreground, const float* background, size_t n,
+                           uint8_t* out);
 /* generateFovMasks for one destination camera at an arbitrary size (DerpUtil.cpp:259-276) */
 int derp_fov_mask(derp_ctx* ctx, int dst, int w, int h, uint8_t* out);
 /* upsampleDisparities for one camera (UpsampleDisparityLib.cpp:98-182). fg_mask / fg_mask_up /
@@ -168,7 +175,7 @@ int derp_get_counters(derp_ctx* ctx, uint64_t* n_cost, uint64_t* n_pair, uint64_
 int derp_reset_counters(derp_ctx* ctx);
 /* per-stage HIP-event timing on the context's own stream, plus per-stage computeCost counters.
  * stage names: "fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject",
- * "proj_bias", "brute_force", "random_proposals", "ping_pong", "bilateral", "median", "mask_fov".
+ * "proj_bias", "brute_force", "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov".
  * level = -1 aggregates all levels. ms / launches / n_cost / n_pair may be NULL. */
 int derp_profile_enable(derp_ctx* ctx, int on);
 int derp_profile_reset(derp_ctx* ctx);

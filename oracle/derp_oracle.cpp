@@ -655,6 +655,83 @@ static void pingPong(Level& L, std::vector<float>* changedPctOut) {
   }
 }
 
+// ---- Derp.cpp:553-748: handleDisparityMismatches (off unless --mismatches_start_level >= level) ----
+static void handleDisparityMismatches(Level& L) {
+  if (L.p.level > L.p.mismatchesStartLevel || L.p.level == L.p.numLevels - 1) {
+    return;
+  }
+  // CHECK_EQ(rigDst.size(), rigSrc.size()): the reference indexes dstDisparity(srcIdx)
+  const float nan = std::numeric_limits<float>::quiet_NaN();
+  std::vector<Img<float>> newDisp(L.D);
+  parallelFor(0, L.D, L.p.threads, [&](int dstIdx) {
+    const Img<float>& dstDisp = L.disparity[dstIdx];
+    Img<uint8_t>& dstMask = L.mismatchMask[dstIdx];
+    Img<float> dstDispNew(L.W, L.H, nan);
+    const Img<float>& dstVar = L.dstVariance(dstIdx);
+    const Camera& camDst = L.rigDst[dstIdx];
+    for (int y = 0; y < L.H; ++y) {
+      for (int x = 0; x < L.W; ++x) {
+        if (!L.fovMask[dstIdx].at(y, x)) {
+          continue;
+        }
+        std::vector<float> dispMatches, dispMismatches;
+        // getSrcMismatches (Derp.cpp:553-603)
+        if (L.dstFg(dstIdx).at(y, x)) {
+          const V3 ptWorld = dstToWorldPoint(camDst, x, y, dstDisp.at(y, x), L.W, L.H);
+          for (int srcIdx = 0; srcIdx < L.S; ++srcIdx) {
+            if (srcIdx == L.dst2src[dstIdx]) {
+              continue;
+            }
+            V2 ptSrc;
+            if (!worldToSrcPoint(ptSrc, ptWorld, L.rigSrc[srcIdx], L.W, L.H)) {
+              continue;
+            }
+            const float dSrc = getPixelBilinear(L.disparity[srcIdx], float(ptSrc.x), float(ptSrc.y));
+            static const float kFractionChange = 0.1f;
+            const float dDstMin = (1.0f - kFractionChange) * dstDisp.at(y, x);
+            const float dDstMax = (1.0f + kFractionChange) * dstDisp.at(y, x);
+            if (dDstMin <= dSrc && dSrc <= dDstMax) {
+              dispMatches.push_back(dSrc);
+            } else {
+              dispMismatches.push_back(dSrc);
+            }
+          }
+        }
+        // updateDstDisparityAndMismatchMask (Derp.cpp:605-652)
+        const float dispCurr = dstDisp.at(y, x);
+        bool mask;
+        float dispNew;
+        if (dispMatches.size() + dispMismatches.size() == 0) {
+          mask = false;
+          dispNew = dispCurr;
+        } else if (
+            int(dispMatches.size()) >= kMinOverlappingCams - 1 || L.varHighThresh < dstVar.at(y, x) ||
+            dstVar.at(y, x) < L.varNoiseFloor) {
+          mask = false;
+          dispNew = dispCurr;
+        } else {
+          mask = true;
+          std::sort(dispMismatches.begin(), dispMismatches.end());
+          int closer;
+          for (closer = 0; closer < int(dispMismatches.size()); ++closer) {
+            if (dispMismatches[closer] >= dispCurr) {
+              break;
+            }
+          }
+          const int median = closer / 2;
+          dispNew = std::min(dispCurr, dispMismatches[median]);
+        }
+        dstMask.at(y, x) = mask;
+        dstDispNew.at(y, x) = dispNew;
+      }
+    }
+    newDisp[dstIdx] = dstDispNew;
+  });
+  for (int d = 0; d < L.D; ++d) {
+    L.disparity[d] = newDisp[d];
+  }
+}
+
 // ---- TemporalBilateralFilter.h:39-124, TGuide = Vec3w ----
 static Img<float> generalizedJointBilateralFilterU16(
     const Img<float>& image,
@@ -1208,12 +1285,28 @@ void oracle_level_median(Level* L) {
 void oracle_level_mask_fov(Level* L) {
   maskFov(*L);
 }
-// Derp.cpp:1005-1034 (mismatch handling off: mismatches_start_level = -1 — not restated)
+void oracle_level_mismatches(Level* L) {
+  handleDisparityMismatches(*L);
+}
+void oracle_level_get_mismatch_mask(Level* L, int d, uint8_t* out) {
+  memcpy(out, L->mismatchMask[d].d.data(), size_t(L->W) * L->H);
+}
+// LayerDisparities.cpp:45-55: mask = fg > 0; layer = fg*mask + bg*(1-mask); imwrite(layer*255) -> 8-bit
+void oracle_layer_disparities(const float* fg, const float* bg, size_t n, uint8_t* out) {
+  for (size_t i = 0; i < n; ++i) {
+    const float mask = fg[i] > 0.0f ? 1.0f : 0.0f;
+    const float layer = fg[i] * mask + bg[i] * (1 - mask);
+    const int r = cvRoundF(layer * 255.0f);
+    out[i] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+  }
+}
+// Derp.cpp:1005-1034
 void oracle_level_process(Level* L) {
   reprojectColors(*L);
   oracle_level_brute_force(L);
   randomProposals(*L);
   pingPong(*L, nullptr);
+  handleDisparityMismatches(*L);
   if (L->p.doBilateral) {
     bilateralFilter(*L);
   }

@@ -249,6 +249,14 @@ class Level:
     def ping_pong(self):
         lib().oracle_level_ping_pong(self.h)
 
+    def mismatches(self):
+        lib().oracle_level_mismatches(self.h)
+
+    def mismatch_mask(self, d):
+        out = np.zeros((self.H, self.W), dtype=np.uint8)
+        lib().oracle_level_get_mismatch_mask(self.h, d, _p(out))
+        return out
+
     def bilateral(self):
         lib().oracle_level_bilateral(self.h)
 
@@ -358,6 +366,14 @@ def temporal_filter(guides, images, masks, frame_offset, sigma, radius, w0, w1, 
     out = np.zeros((h, w), dtype=np.float32)
     lib().oracle_temporal_filter(gp, ip, mp, n, w, h, frame_offset, C.c_float(sigma), radius, C.c_float(w0),
                                  C.c_float(w1), C.c_float(w2), threads, _p(out))
+    return out
+
+
+def layer_disparities(fg, bg):
+    fg = np.ascontiguousarray(fg, dtype=np.float32)
+    bg = np.ascontiguousarray(bg, dtype=np.float32)
+    out = np.zeros(fg.shape, dtype=np.uint8)
+    lib().oracle_layer_disparities(_p(fg), _p(bg), C.c_size_t(fg.size), _p(out))
     return out
 
 

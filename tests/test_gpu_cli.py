@@ -180,3 +180,24 @@ def test_upsample_cli(dataset, tmp_path):
         got = dio.read_pfm(os.path.join(up_b, cam, "000000.pfm"))
         assert common.compare_disparity(got, ref, 1e-5)[0] == 0, cam
         assert os.path.exists(os.path.join(up_b, cam, "000000.png"))
+
+
+def test_layer_disparities_cli(dataset, tmp_path):
+    from facebook360_dep_amd import imageio as dio
+    from oracle import oracle_lib as O
+
+    out = str(tmp_path / "out")
+    run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + out, "--partial_coverage", "--resolution=96",
+        "--use_foreground_masks", "--level_end=0", "--save_debug_images")
+    fgdir = os.path.join(out, "disparity_levels", "level_0")
+    bgdir = os.path.join(dataset["root"], "background", "disparity_levels", "level_0")
+    layered = str(tmp_path / "layered")
+    run("LayerDisparities", "--rig=" + os.path.join(dataset["root"], "rigs", "rig_calibrated.json"),
+        "--background_disp=" + bgdir, "--foreground_disp=" + fgdir, "--output=" + layered)
+    for cam in (c["id"] for c in dataset["rig"]["cameras"]):
+        fg = dio.read_pfm(os.path.join(fgdir, cam, "000000.pfm"))
+        bg = dio.read_pfm(os.path.join(bgdir, cam, "000000.pfm"))
+        got = dio.read_png(os.path.join(layered, "disparity", cam, "000000.png"))
+        assert got.dtype == np.uint8 and np.array_equal(got, O.layer_disparities(fg, bg))
+        for t in ("cost", "confidence", "mismatches"):
+            assert os.path.exists(os.path.join(out, t, "level_0", cam, "000000.png"))

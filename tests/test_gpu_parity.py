@@ -358,3 +358,53 @@ def test_config2_full_size_properties(built):
         assert pp <= 9 * interior and pp >= 0.9 * 9 * interior  # textured scene: nearly every pixel passes the variance gate
         assert rp <= 3 * interior and rp % 3 == 0
     g.close()
+
+
+def test_mismatch_handling(small):
+    """handleDisparityMismatches (Derp.cpp:553-748, --mismatches_start_level): the only stage in which
+    one destination reads the other cameras' disparities."""
+    from facebook360_dep_amd import derp
+
+    opts = dict(partial_coverage=True, mismatches_start_level=1)
+    # stage level, from identical inputs
+    level = 0
+    rng = np.random.default_rng(4)
+    w, h = small["sizes"][level]
+    start = [(small["frame"]["truth"][d] * rng.uniform(0.7, 1.4, size=(h, w))).astype(np.float32)
+             for d in range(small["n"])]
+    L = common.oracle_level(small["rig"], small["sizes"], small["frame"], level, small["res"], small["res"], **opts)
+    g = derp.Derp(small["rig"]["cameras"], partial_coverage=1, mismatches_start_level=1)
+    g.set_pyramid(small["sizes"], small["res"], small["res"])
+    g.upload_frame({"color": small["frame"]["color"]})
+    g.level_begin(level)
+    for d in range(small["n"]):
+        L.set_dst(d, disparity=start[d])
+        g.set_level_disparity(d, start[d])
+    L.mismatches()
+    g.stage("mismatches")
+    flagged = 0
+    for d in range(small["n"]):
+        assert _float_equal(g.get_level_disparity(d), L.get_dst(d)[0]) == 0, d
+        assert np.array_equal(g.mismatch_mask(d), L.mismatch_mask(d)), d
+        flagged += int(L.mismatch_mask(d).sum())
+    assert flagged > 0, "no pixel was flagged: the test would be vacuous"
+    # whole pyramid with the stage switched on
+    ref = common.oracle_pyramid(small["rig"], small["sizes"], small["frame"], small["res"], small["res"], **opts)
+    g.process_pyramid()
+    g.synchronize()
+    for d in range(small["n"]):
+        bad, rel = common.compare_disparity(g.download_disparity(0, d), ref[0][d], TOL)
+        assert bad == 0, (d, bad, rel)
+    assert g.profile_query("mismatches", 0)["launches"] >= 0
+    g.close()
+
+
+def test_layer_disparities(gpu):
+    from oracle import oracle_lib as O
+
+    rng = np.random.default_rng(8)
+    fg = rng.uniform(-0.2, 1.3, size=(37, 53)).astype(np.float32)
+    fg[rng.random(fg.shape) < 0.2] = np.nan
+    fg[rng.random(fg.shape) < 0.1] = 0.0
+    bg = rng.uniform(0.0, 1.1, size=fg.shape).astype(np.float32)
+    assert np.array_equal(gpu.layer_disparities(fg, bg), O.layer_disparities(fg, bg))
