@@ -83,6 +83,11 @@ struct LanczosTab {
   DevBuf ofs, coef;
 };
 
+struct AreaTabDev {  // computeResizeAreaTab of one axis, resident in HBM
+  DevBuf start, si, alpha;
+  int iscale = 0;
+};
+
 }  // namespace
 
 struct derp_ctx {
@@ -110,6 +115,8 @@ struct derp_ctx {
   bool tablesValid = false;
   DevBuf counters;  // [ST_COUNT][kMaxLevels][4] u64
   std::map<std::pair<int, int>, LanczosTab*> lanczos;
+  std::map<std::pair<int, int>, AreaTabDev*> areaTabs;
+  DevBuf fullFrame;
   DevBuf spiral;
   int spiralN = 0, spiralRadius = -1;
 
@@ -295,6 +302,86 @@ int get_lanczos(derp_ctx* c, int ssize, int dsize, LanczosTab** out) {
   HIPCHK(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
   c->lanczos[key] = t;
   *out = t;
+  return 0;
+}
+
+// cv::resize INTER_AREA, one axis: resize.cpp computeResizeAreaTab (fractional scales) or the integer
+// scale factor of the "area fast" paths (|scale - round(scale)| < DBL_EPSILON)
+int get_area_tab(derp_ctx* c, int ssize, int dsize, AreaTabDev** out) {
+  auto key = std::make_pair(ssize, dsize);
+  auto it = c->areaTabs.find(key);
+  if (it != c->areaTabs.end()) {
+    *out = it->second;
+    return 0;
+  }
+  AreaTabDev* t = new AreaTabDev;
+  const double scale = (double)ssize / dsize;
+  const int iscale = (int)std::nearbyint(scale);
+  std::vector<int> start(dsize + 1, 0), si;
+  std::vector<float> alpha;
+  if (iscale >= 1 && std::abs(scale - iscale) < 2.220446049250313e-16) {
+    t->iscale = iscale;
+  } else {
+    for (int dx = 0; dx < dsize; ++dx) {
+      start[dx] = (int)si.size();
+      const double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+      const double cellWidth = std::min(scale, ssize - fsx1);
+      int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+      sx2 = std::min(sx2, ssize - 1);
+      sx1 = std::min(sx1, sx2);
+      if (sx1 - fsx1 > 1e-3) {
+        si.push_back(sx1 - 1);
+        alpha.push_back((float)((sx1 - fsx1) / cellWidth));
+      }
+      for (int sx = sx1; sx < sx2; ++sx) {
+        si.push_back(sx);
+        alpha.push_back(float(1.0 / cellWidth));
+      }
+      if (fsx2 - sx2 > 1e-3) {
+        si.push_back(sx2);
+        alpha.push_back((float)(std::min(std::min(fsx2 - sx2, 1.), cellWidth) / cellWidth));
+      }
+    }
+    start[dsize] = (int)si.size();
+  }
+  if (si.empty()) {
+    si.push_back(0);
+    alpha.push_back(0.f);
+  }
+  ALLOC(c, t->start, start.size() * sizeof(int));
+  ALLOC(c, t->si, si.size() * sizeof(int));
+  ALLOC(c, t->alpha, alpha.size() * sizeof(float));
+  HIPCHK(c, hipMemcpy(t->start.p, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(t->si.p, si.data(), si.size() * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(t->alpha.p, alpha.data(), alpha.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->areaTabs[key] = t;
+  *out = t;
+  return 0;
+}
+
+// cv2.resize(src, (dw, dh), INTER_AREA): kind 0 BGR u16 -> BGRX, 1 u8 (-> {0,1} when threshold >= 0), 2 f32
+int resize_area_dev(derp_ctx* c, int kind, const void* src, int sw, int sh, void* dst, int dw, int dh, int threshold) {
+  if (dw > sw || dh > sh) {
+    return fail(c, "pyramid levels must not be larger than the full-size frame (%dx%d -> %dx%d)", sw, sh, dw, dh);
+  }
+  AreaTabDev *tx, *ty;
+  TRY(get_area_tab(c, sw, dw, &tx));
+  TRY(get_area_tab(c, sh, dh, &ty));
+  AreaAxis ax{tx->start.as<int>(), tx->si.as<int>(), tx->alpha.as<float>(), tx->iscale};
+  AreaAxis ay{ty->start.as<int>(), ty->si.as<int>(), ty->alpha.as<float>(), ty->iscale};
+  if ((ax.iscale > 0) != (ay.iscale > 0)) {
+    // cv::resize takes the table path unless BOTH scales are integers; build the missing table
+    return fail(c, "mixed integer / fractional area scales (%dx%d -> %dx%d) are not supported", sw, sh, dw, dh);
+  }
+  const dim3 g = grid2d(dw, dh, 1, kBlk2d);
+  if (kind == 0) {
+    hipLaunchKernelGGL(k_resize_area<0>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
+  } else if (kind == 1) {
+    hipLaunchKernelGGL(k_resize_area<1>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
+  } else {
+    hipLaunchKernelGGL(k_resize_area<2>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
+  }
+  KCHECK(c);
   return 0;
 }
 
@@ -853,6 +940,13 @@ void derp_destroy(derp_ctx* c) {
     kv.second->coef.release();
     delete kv.second;
   }
+  for (auto& kv : c->areaTabs) {
+    kv.second->start.release();
+    kv.second->si.release();
+    kv.second->alpha.release();
+    delete kv.second;
+  }
+  c->fullFrame.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1178,6 +1272,107 @@ int derp_debug_download(derp_ctx* c, int d, int s, int which, void* out) {
     return 0;
   }
   return fail(c, "unknown table id %d", which);
+}
+
+// ---- pyramid builder (scripts/render/resize.py:51-85) ----
+static int build_pyramid(derp_ctx* c, int kind, int index, int count, const void* host, size_t elem, int w, int h,
+                         int threshold) {
+  if (!c || c->numLevels == 0) {
+    return fail(c, "derp_set_pyramid has not been called");
+  }
+  if (index < 0 || index >= count || !host || w <= 0 || h <= 0) {
+    return fail(c, "bad camera index / null image");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  ALLOC(c, c->fullFrame, n * elem);
+  HIPCHK(c, hipMemcpyAsync(c->fullFrame.p, host, n * elem, hipMemcpyHostToDevice, c->stream));
+  for (int l = 0; l < c->numLevels; ++l) {
+    const size_t nl = npx(c, l);
+    if (nl == 0) {
+      continue;
+    }
+    void* dst = kind == 0 ? (void*)(c->pyrColor[l].as<ushort4>() + (size_t)index * nl)
+        : kind == 1       ? (void*)(c->pyrFg[l].as<uint8_t>() + (size_t)index * nl)
+                          : (void*)(c->pyrBg[l].as<float>() + (size_t)index * nl);
+    TRY(resize_area_dev(c, kind, c->fullFrame.p, w, h, dst, c->LW[l], c->LH[l], threshold));
+    if (kind == 2) {
+      c->haveBg[l] = 1;
+    }
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // fullFrame is reused by the next call
+  return 0;
+}
+int derp_build_pyramid_color(derp_ctx* c, int src, const uint16_t* bgr, int w, int h) {
+  return build_pyramid(c, 0, src, c ? c->S : 0, bgr, 6, w, h, -1);
+}
+int derp_build_pyramid_foreground_mask(derp_ctx* c, int src, const uint8_t* mask, int w, int h, int threshold) {
+  return build_pyramid(c, 1, src, c ? c->S : 0, mask, 1, w, h, threshold);
+}
+int derp_build_pyramid_background_disparity(derp_ctx* c, int dst, const float* disp, int w, int h) {
+  return build_pyramid(c, 2, dst, c ? c->D : 0, disp, 4, w, h, -1);
+}
+int derp_download_level_color(derp_ctx* c, int level, int src, uint16_t* bgr) {
+  TRY(check_level(c, level));
+  if (src < 0 || src >= c->S || !bgr) {
+    return fail(c, "bad source index / null output");
+  }
+  const size_t n = npx(c, level);
+  ALLOC(c, c->staging, n * 6);
+  hipLaunchKernelGGL(k_bgrx_to_bgr, dim3(flat_grid(n)), dim3(256), 0, c->stream,
+                     c->pyrColor[level].as<ushort4>() + (size_t)src * n, c->staging.as<uint16_t>(), n);
+  KCHECK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(bgr, c->staging.p, n * 6, hipMemcpyDeviceToHost));
+  return 0;
+}
+int derp_download_level_mask(derp_ctx* c, int level, int src, uint8_t* mask) {
+  TRY(check_level(c, level));
+  if (src < 0 || src >= c->S || !mask) {
+    return fail(c, "bad source index / null output");
+  }
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(mask, c->pyrFg[level].as<uint8_t>() + (size_t)src * n, n, hipMemcpyDeviceToHost));
+  return 0;
+}
+int derp_download_level_background(derp_ctx* c, int level, int dst, float* disp) {
+  TRY(check_level(c, level));
+  if (dst < 0 || dst >= c->D || !disp) {
+    return fail(c, "bad destination index / null output");
+  }
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(disp, c->pyrBg[level].as<float>() + (size_t)dst * n, n * 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+// one image: kind 0 = BGR u16 x3, 1 = u8, 2 = f32 (host in / host out)
+int derp_resize_area(derp_ctx* c, int kind, const void* src, int w, int h, void* dst, int dw, int dh) {
+  if (!c || !src || !dst || kind < 0 || kind > 2 || w <= 0 || h <= 0 || dw <= 0 || dh <= 0) {
+    return fail(c, "bad arguments");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t elem = kind == 0 ? 6 : kind == 1 ? 1 : 4, n = (size_t)w * h, nd = (size_t)dw * dh;
+  DevBuf in, out, out3;
+  int rc = 0;
+  if (in.ensure(n * elem) || out.ensure(nd * (kind == 0 ? 8 : elem)) || (kind == 0 && out3.ensure(nd * 6))) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(in.p, src, n * elem, hipMemcpyHostToDevice);
+    rc = resize_area_dev(c, kind, in.p, w, h, out.p, dw, dh, -1);
+    if (!rc && kind == 0) {
+      hipLaunchKernelGGL(k_bgrx_to_bgr, dim3(flat_grid(nd)), dim3(256), 0, c->stream, out.as<ushort4>(),
+                         out3.as<uint16_t>(), nd);
+    }
+    if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess ||
+                hipMemcpy(dst, kind == 0 ? out3.p : out.p, nd * elem, hipMemcpyDeviceToHost) != hipSuccess)) {
+      rc = fail(c, "HIP error in derp_resize_area: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* b : {&in, &out, &out3}) {
+    b->release();
+  }
+  return rc;
 }
 
 // ---- sibling binaries' kernels, host-pointer convenience forms ----

@@ -1318,6 +1318,114 @@ __global__ void k_spiral_fill(const float* __restrict__ dispUp, const float* __r
 }
 
 // ----------------------------------------------------------------------------------------
+// pyramid builder — scripts/render/resize.py:51-85: cv2.resize(full frame, (w, h), INTER_AREA) per
+// level (+ threshold 127 for masks). cv::resize's three INTER_AREA code paths when shrinking:
+// 2x2 integer average (a+b+c+d+2)>>2 on 8U/16U, float block sum * (1/area) for other integer
+// scales, and the fractional-scale tables of computeResizeAreaTab (built on the host).
+//   KIND 0: BGR u16 interleaved in -> BGRX ushort4 out (the pyramid's colour layout)
+//   KIND 1: u8 in -> u8 {0,1} out = (resized > threshold)        (fg masks: threshold 127)
+//   KIND 2: f32 in -> f32 out                                     (background disparity)
+// ----------------------------------------------------------------------------------------
+struct AreaAxis {
+  const int* start;    // [dsize + 1] first table entry of each output index
+  const int* si;       // source index per entry
+  const float* alpha;  // weight per entry
+  int iscale;          // integer scale factor, or 0 when fractional
+};
+
+template <int KIND>
+__device__ __forceinline__ float area_src(const void* src, size_t pix, int c) {
+  if (KIND == 0) {
+    return (float)reinterpret_cast<const uint16_t*>(src)[pix * 3 + c];
+  } else if (KIND == 1) {
+    return (float)reinterpret_cast<const uint8_t*>(src)[pix];
+  } else {
+    return reinterpret_cast<const float*>(src)[pix];
+  }
+}
+
+template <int KIND>
+__global__ void k_resize_area(const void* __restrict__ src, int SW, int SH, void* __restrict__ dst, int DW, int DH,
+                              AreaAxis ax, AreaAxis ay, int threshold) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (dx >= DW || dy >= DH) {
+    return;
+  }
+  constexpr int CN = KIND == 0 ? 3 : 1;
+  float res[CN];
+  if (SW == DW && SH == DH) {
+    for (int c = 0; c < CN; ++c) {
+      res[c] = area_src<KIND>(src, (size_t)dy * SW + dx, c);
+    }
+  } else if (ax.iscale > 0 && ay.iscale > 0) {
+    if (ax.iscale == 2 && ay.iscale == 2 && KIND != 2) {
+      for (int c = 0; c < CN; ++c) {
+        const size_t p = (size_t)(2 * dy) * SW + 2 * dx;
+        const int v = (int)area_src<KIND>(src, p, c) + (int)area_src<KIND>(src, p + 1, c) +
+            (int)area_src<KIND>(src, p + SW, c) + (int)area_src<KIND>(src, p + SW + 1, c);
+        res[c] = (float)((v + 2) >> 2);
+      }
+    } else {
+      const float scale = 1.f / (float)(ax.iscale * ay.iscale);
+      for (int c = 0; c < CN; ++c) {
+        float sum = 0;
+        for (int sy = 0; sy < ay.iscale; ++sy) {
+          for (int sx = 0; sx < ax.iscale; ++sx) {
+            sum += area_src<KIND>(src, (size_t)(dy * ay.iscale + sy) * SW + dx * ax.iscale + sx, c);
+          }
+        }
+        res[c] = sum * scale;
+      }
+    }
+  } else {
+    float sum[CN];
+    const int y0 = ay.start[dy], y1 = ay.start[dy + 1], x0 = ax.start[dx], x1 = ax.start[dx + 1];
+    for (int j = y0; j < y1; ++j) {
+      const float beta = ay.alpha[j];
+      const size_t row = (size_t)ay.si[j] * SW;
+      float buf[CN];
+      for (int c = 0; c < CN; ++c) {
+        buf[c] = 0.f;
+      }
+      for (int k = x0; k < x1; ++k) {
+        const float a = ax.alpha[k];
+        for (int c = 0; c < CN; ++c) {
+          buf[c] += area_src<KIND>(src, row + ax.si[k], c) * a;
+        }
+      }
+      for (int c = 0; c < CN; ++c) {
+        sum[c] = (j == y0) ? beta * buf[c] : sum[c] + beta * buf[c];
+      }
+    }
+    for (int c = 0; c < CN; ++c) {
+      res[c] = sum[c];
+    }
+  }
+  const size_t o = (size_t)dy * DW + dx;
+  if (KIND == 0) {
+    reinterpret_cast<ushort4*>(dst)[o] =
+        make_ushort4((unsigned short)min(max(cv_round(res[0]), 0), 65535), (unsigned short)min(max(cv_round(res[1]), 0), 65535),
+                     (unsigned short)min(max(cv_round(res[2]), 0), 65535), 0);
+  } else if (KIND == 1) {
+    const int v = min(max(cv_round(res[0]), 0), 255);
+    reinterpret_cast<uint8_t*>(dst)[o] = threshold >= 0 ? (uint8_t)(v > threshold) : (uint8_t)v;
+  } else {
+    reinterpret_cast<float*>(dst)[o] = res[0];
+  }
+}
+
+__global__ void k_bgrx_to_bgr(const ushort4* __restrict__ in, uint16_t* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const ushort4 q = in[i];
+    out[3 * i] = q.x;
+    out[3 * i + 1] = q.y;
+    out[3 * i + 2] = q.z;
+  }
+}
+
+// ----------------------------------------------------------------------------------------
 // temporal joint bilateral — TemporalBilateralFilter.h:126-172 (quirks kept: accumulates the
 // CENTRE pixel of frame t, int colour difference / 65535.f, no sumWeight == 0 guard)
 // ----------------------------------------------------------------------------------------

@@ -37,6 +37,8 @@ class Options(C.Structure):
 # every symbol include/derp_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "derp_options_default", "derp_create", "derp_destroy", "derp_last_error", "derp_set_options", "derp_set_pyramid",
+    "derp_build_pyramid_color", "derp_build_pyramid_foreground_mask", "derp_build_pyramid_background_disparity",
+    "derp_download_level_color", "derp_download_level_mask", "derp_download_level_background", "derp_resize_area",
     "derp_upload_color", "derp_upload_foreground_mask", "derp_upload_background_disparity", "derp_upload_disparity",
     "derp_process_level", "derp_process_pyramid", "derp_synchronize", "derp_download_disparity", "derp_download_cost",
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
@@ -184,6 +186,42 @@ class Derp:
         disp = np.ascontiguousarray(disp, dtype=np.float32)
         assert disp.shape == self._shape(level)
         self._ck(lib().derp_upload_disparity(self.h, level, d, _p(disp)))
+
+    # ---- pyramid builder (scripts/render/resize.py)
+    def build_pyramid_color(self, s, bgr):
+        bgr = np.ascontiguousarray(bgr, dtype=np.uint16)
+        self._ck(lib().derp_build_pyramid_color(self.h, s, _p(bgr), bgr.shape[1], bgr.shape[0]))
+
+    def build_pyramid_foreground_mask(self, s, mask_u8, threshold=127):
+        mask_u8 = np.ascontiguousarray(mask_u8, dtype=np.uint8)
+        self._ck(lib().derp_build_pyramid_foreground_mask(self.h, s, _p(mask_u8), mask_u8.shape[1], mask_u8.shape[0],
+                                                          threshold))
+
+    def build_pyramid_background_disparity(self, d, disp):
+        disp = np.ascontiguousarray(disp, dtype=np.float32)
+        self._ck(lib().derp_build_pyramid_background_disparity(self.h, d, _p(disp), disp.shape[1], disp.shape[0]))
+
+    def download_level_color(self, level, s):
+        out = np.zeros(self._shape(level) + (3,), dtype=np.uint16)
+        self._ck(lib().derp_download_level_color(self.h, level, s, _p(out)))
+        return out
+
+    def download_level_mask(self, level, s):
+        out = np.zeros(self._shape(level), dtype=np.uint8)
+        self._ck(lib().derp_download_level_mask(self.h, level, s, _p(out)))
+        return out
+
+    def download_level_background(self, level, d):
+        out = np.zeros(self._shape(level), dtype=np.float32)
+        self._ck(lib().derp_download_level_background(self.h, level, d, _p(out)))
+        return out
+
+    def resize_area(self, src, dw, dh):
+        src = np.ascontiguousarray(src)
+        kind = {(np.dtype(np.uint16), 3): 0, (np.dtype(np.uint8), 2): 1, (np.dtype(np.float32), 2): 2}[(src.dtype, src.ndim)]
+        out = np.zeros((dh, dw, 3) if kind == 0 else (dh, dw), dtype=src.dtype)
+        self._ck(lib().derp_resize_area(self.h, kind, _p(src), src.shape[1], src.shape[0], _p(out), dw, dh))
+        return out
 
     def upload_frame(self, frame):
         """frame: dict from synth.make_frame (color[level][cam], optional masks / bg_disp)."""

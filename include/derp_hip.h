@@ -91,6 +91,21 @@ int derp_upload_background_disparity(derp_ctx* ctx, int level, int dst, const fl
 /* disparity of an already-finished level (resume from disk: DerpCLI.cpp:153-155,276-303) */
 int derp_upload_disparity(derp_ctx* ctx, int level, int dst, const float* disp);
 
+/* ---- pyramid builder: the step before the path (scripts/render/resize.py:51-85 resize_camera) --
+ * cv2.resize(full-size frame, (w_L, h_L), INTER_AREA) into every level declared in derp_set_pyramid;
+ * the frame crosses PCIe once and all its levels are produced in HBM. Masks: 8-bit image, resized,
+ * then `> threshold` (resize.py passes 127; DerpCLI re-thresholds at 127, CvUtil.h:235-239). */
+int derp_build_pyramid_color(derp_ctx* ctx, int src, const uint16_t* bgr, int w, int h);
+int derp_build_pyramid_foreground_mask(derp_ctx* ctx, int src, const uint8_t* mask, int w, int h,
+                                       int threshold);
+int derp_build_pyramid_background_disparity(derp_ctx* ctx, int dst, const float* disp, int w, int h);
+/* read a level back (what resize.py writes to level_<L>/<cam>/<frame>) */
+int derp_download_level_color(derp_ctx* ctx, int level, int src, uint16_t* bgr);
+int derp_download_level_mask(derp_ctx* ctx, int level, int src, uint8_t* mask01);
+int derp_download_level_background(derp_ctx* ctx, int level, int dst, float* disp);
+/* one image: kind 0 = BGR u16 x3, 1 = u8 x1, 2 = f32 x1 */
+int derp_resize_area(derp_ctx* ctx, int kind, const void* src, int w, int h, void* dst, int dw, int dh);
+
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* One (frame, level): generateFovMasks (DerpUtil.cpp:259-276) + PyramidLevel ctor's
  * computeVariances (PyramidLevel.h:232-247) + precomputeProjections (Derp.cpp:955-976) +

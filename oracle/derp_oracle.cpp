@@ -1513,6 +1513,16 @@ void oracle_cv_variance(const uint16_t* src, int w, int h, float* out) {
   const Img<float> v = computeImageVariance(s);
   memcpy(out, v.d.data(), size_t(w) * h * 4);
 }
+// pyramid builder: scripts/render/resize.py:51-85 — cv2.resize(full frame, (w, h), INTER_AREA) per level
+void oracle_cv_resize_area_u16c3(const uint16_t* src, int sw, int sh, int dw, int dh, uint16_t* out) {
+  resizeAreaCv<uint16_t, 3>(src, sw, sh, out, dw, dh);
+}
+void oracle_cv_resize_area_u8(const uint8_t* src, int sw, int sh, int dw, int dh, uint8_t* out) {
+  resizeAreaCv<uint8_t, 1>(src, sw, sh, out, dw, dh);
+}
+void oracle_cv_resize_area_f32(const float* src, int sw, int sh, int dw, int dh, float* out) {
+  resizeAreaCv<float, 1>(src, sw, sh, out, dw, dh);
+}
 // libstdc++ behaviours the random-proposal stage depends on (Derp.cpp:757-758,806-808)
 void oracle_minstd_uniform(int seed, int n, float a, float b, float* out) {
   std::default_random_engine engine;

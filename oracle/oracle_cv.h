@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
+#include <type_traits>
 #include <vector>
 
 namespace oracle {
@@ -413,6 +414,58 @@ resizeAreaGeneric(const T* src, int sw, int sh, int dw, int dh, T* dst, Cast cas
   if (prev_dy >= 0) {
     flush(prev_dy);
   }
+}
+
+// cv::resize(..., INTER_AREA) as resize.cpp dispatches it when shrinking:
+//   * both scale factors integer ("is_area_fast"):
+//       - scale 2x2 on 8U/16U: ResizeAreaFastVec_SIMD_*: (a + b + c + d + 2) >> 2
+//       - otherwise ResizeAreaFast_<T, float>: float sum over the block in row-major order, * (1.f / area),
+//         saturate_cast<T> (round-half-even for integers)
+//   * fractional scale: computeResizeAreaTab + ResizeArea_Invoker (resizeAreaGeneric above)
+// CN interleaved channels. castI = integer rounding cast (u8 / u16); floats pass through.
+template <typename T, int CN>
+static inline void resizeAreaCv(const T* src, int sw, int sh, T* dst, int dw, int dh) {
+  const double scale_x = (double)sw / dw, scale_y = (double)sh / dh;
+  const int iscale_x = (int)std::nearbyint(scale_x) < 1 ? 1 : cvRoundD(scale_x);
+  const int iscale_y = cvRoundD(scale_y) < 1 ? 1 : cvRoundD(scale_y);
+  const bool fast = std::abs(scale_x - iscale_x) < 2.220446049250313e-16 && std::abs(scale_y - iscale_y) < 2.220446049250313e-16;
+  auto cast = [](float v) -> T {
+    if (std::is_same<T, float>::value) {
+      return (T)v;
+    }
+    const int r = cvRoundF(v);
+    const int hi = std::is_same<T, uint8_t>::value ? 255 : 65535;
+    return (T)(r < 0 ? 0 : r > hi ? hi : r);
+  };
+  if (sw == dw && sh == dh) {
+    memcpy(dst, src, sizeof(T) * (size_t)sw * sh * CN);
+    return;
+  }
+  if (fast) {
+    const int area = iscale_x * iscale_y;
+    const float scale = 1.f / area;
+    for (int dy = 0; dy < dh; ++dy) {
+      for (int dx = 0; dx < dw; ++dx) {
+        for (int c = 0; c < CN; ++c) {
+          if (iscale_x == 2 && iscale_y == 2 && !std::is_same<T, float>::value) {
+            const T* r0 = src + ((size_t)(2 * dy) * sw + 2 * dx) * CN + c;
+            const T* r1 = r0 + (size_t)sw * CN;
+            dst[((size_t)dy * dw + dx) * CN + c] = (T)(((int)r0[0] + (int)r0[CN] + (int)r1[0] + (int)r1[CN] + 2) >> 2);
+          } else {
+            float sum = 0;
+            for (int sy = 0; sy < iscale_y; ++sy) {
+              for (int sx = 0; sx < iscale_x; ++sx) {
+                sum += (float)src[((size_t)(dy * iscale_y + sy) * sw + dx * iscale_x + sx) * CN + c];
+              }
+            }
+            dst[((size_t)dy * dw + dx) * CN + c] = cast(sum * scale);
+          }
+        }
+      }
+    }
+    return;
+  }
+  resizeAreaGeneric<T, CN>(src, sw, sh, dw, dh, dst, cast);
 }
 
 } // namespace oracle

@@ -201,3 +201,33 @@ def test_layer_disparities_cli(dataset, tmp_path):
         assert got.dtype == np.uint8 and np.array_equal(got, O.layer_disparities(fg, bg))
         for t in ("cost", "confidence", "mismatches"):
             assert os.path.exists(os.path.join(out, t, "level_0", cam, "000000.png"))
+
+
+def test_resize_module_builds_level_directories(dataset, tmp_path):
+    """python -m facebook360_dep_amd.resize — the GPU twin of scripts/render/resize.py: full-size frames
+    in <src>/<cam>/, level_<L>/<cam>/<frame>.png out, identical to the oracle's cv2.INTER_AREA restatement."""
+    import sys
+
+    from facebook360_dep_amd import imageio as dio
+    from oracle import oracle_lib as O
+
+    src = tmp_path / "color"
+    rig = {"cameras": [dict(c, resolution=[512, 512]) for c in dataset["rig"]["cameras"][:2]]}
+    rng = np.random.default_rng(12)
+    imgs = {}
+    for cam in rig["cameras"]:
+        os.makedirs(src / cam["id"])
+        imgs[cam["id"]] = rng.integers(0, 65536, size=(512, 512, 3)).astype(np.uint16)
+        dio.write_png16(str(src / cam["id"] / "000000.png"), imgs[cam["id"]])
+    rigf = tmp_path / "rig.json"
+    rigf.write_text(__import__("json").dumps(rig))
+    dst = tmp_path / "levels"
+    p = subprocess.run([sys.executable, "-m", "facebook360_dep_amd.resize", "--src_dir", str(src), "--dst_dir", str(dst),
+                        "--rig", str(rigf)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    widths = [2048, 1024, 512, 256, 200, 128, 100, 80, 60, 50]
+    assert sorted(os.listdir(dst)) == sorted("level_%d" % i for i in range(10))
+    for level in (2, 3, 4, 9):  # levels 0-1 would upsample a 512-px frame; resize.py is only run on larger inputs
+        for cam in imgs:
+            got = dio.read_png(str(dst / ("level_%d" % level) / cam / "000000.png"))
+            assert np.array_equal(got, O.cv_resize_area(imgs[cam], widths[level], widths[level])), (level, cam)

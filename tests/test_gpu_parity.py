@@ -408,3 +408,45 @@ def test_layer_disparities(gpu):
     fg[rng.random(fg.shape) < 0.1] = 0.0
     bg = rng.uniform(0.0, 1.1, size=fg.shape).astype(np.float32)
     assert np.array_equal(gpu.layer_disparities(fg, bg), O.layer_disparities(fg, bg))
+
+
+def test_pyramid_builder(built):
+    """scripts/render/resize.py on the GPU: one full-size frame in, every level in HBM; then the depth
+    path on the built pyramid equals the oracle fed with the oracle-built pyramid."""
+    from facebook360_dep_amd import derp, synth
+    from oracle import oracle_lib as O
+
+    res = 256
+    rig = synth.make_rig(4, res)
+    sizes = synth.level_sizes(res, res, [256, 200, 128, 100, 80, 60, 50])
+    full = synth.make_frame(rig, [(res, res)], with_masks=True)
+    g = derp.Derp(rig["cameras"], partial_coverage=1, use_foreground_masks=1)
+    g.set_pyramid(sizes, res, res)
+    color = [[None] * 4 for _ in sizes]
+    masks = [[None] * 4 for _ in sizes]
+    bgd = [[None] * 4 for _ in sizes]
+    for s in range(4):
+        m255 = full["masks"][0][s] * 255
+        g.build_pyramid_color(s, full["color"][0][s])
+        g.build_pyramid_foreground_mask(s, m255, 127)
+        g.build_pyramid_background_disparity(s, full["bg_disp"][0][s])
+        for li, (w, h) in enumerate(sizes):
+            color[li][s] = O.cv_resize_area(full["color"][0][s], w, h)
+            masks[li][s] = (O.cv_resize_area(m255, w, h) > 127).astype(np.uint8)
+            bgd[li][s] = O.cv_resize_area(full["bg_disp"][0][s], w, h)
+            assert np.array_equal(g.download_level_color(li, s), color[li][s]), ("colour", li, s)
+            assert np.array_equal(g.download_level_mask(li, s), masks[li][s]), ("mask", li, s)
+            assert _float_equal(g.download_level_background(li, s), bgd[li][s]) == 0, ("background", li, s)
+    # stand-alone entry point, incl. a non-square fractional case
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 65536, size=(216, 336, 3)).astype(np.uint16)
+    for dw, dh in ((168, 108), (100, 64), (50, 32)):
+        assert np.array_equal(g.resize_area(img, dw, dh), O.cv_resize_area(img, dw, dh)), (dw, dh)
+    frame = {"color": color, "masks": masks, "bg_disp": bgd}
+    ref = common.oracle_pyramid(rig, sizes, frame, res, res, partial_coverage=True, use_foreground_masks=True)
+    g.process_pyramid()
+    g.synchronize()
+    for d in range(4):
+        bad, rel = common.compare_disparity(g.download_disparity(0, d), ref[0][d], TOL)
+        assert bad == 0, (d, bad, rel)
+    g.close()

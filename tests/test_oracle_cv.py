@@ -159,3 +159,24 @@ def test_pfm_and_png_io(tmp_path):
         assert np.array_equal(np.asarray(Image.open(q)), mask * 255)  # a third-party decoder agrees
     except ImportError:
         pass
+
+
+def test_resize_area_paths_vs_exact_area_average():
+    """cv2.resize INTER_AREA restatement (integer 2x2, integer NxN, fractional tables) against an exact
+    float64 area average: never more than one rounding step apart."""
+    from facebook360_dep_amd import synth
+
+    img = rng.integers(0, 65536, size=(240, 320, 3)).astype(np.uint16)
+    for dw, dh in ((160, 120), (80, 60), (40, 30), (100, 76), (50, 38), (320, 240)):
+        got = O.cv_resize_area(img, dw, dh).astype(np.float64)
+        ref = synth.resize_area(img, dw, dh)
+        assert np.abs(got - ref).max() <= 0.5 + 1e-2, (dw, dh)
+    # 2x2 integer path rounds half up: (a+b+c+d+2)>>2
+    blk = np.array([[1, 2], [2, 1]], dtype=np.uint16)  # sum 6 -> (6+2)>>2 = 2
+    tile = np.tile(blk[:, :, None], (4, 4, 3))
+    assert (O.cv_resize_area(tile, 4, 4) == 2).all()
+    msk = (rng.random((240, 320)) > 0.5).astype(np.uint8) * 255
+    assert np.abs(O.cv_resize_area(msk, 100, 76).astype(np.float64) - synth.resize_area(msk, 100, 76)).max() <= 0.51
+    f = rng.random((240, 320)).astype(np.float32)
+    for dw, dh in ((160, 120), (100, 76), (40, 30)):
+        assert np.abs(O.cv_resize_area(f, dw, dh) - synth.resize_area(f, dw, dh)).max() < 1e-6
