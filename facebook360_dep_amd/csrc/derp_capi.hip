@@ -1375,6 +1375,49 @@ int derp_resize_area(derp_ctx* c, int kind, const void* src, int w, int h, void*
   return rc;
 }
 
+// ---- GenerateForegroundMasks (source/render/BackgroundSubtractionUtil.h:20-60) ----
+int derp_generate_foreground_mask(derp_ctx* c, const uint16_t* template_bgr, const uint16_t* frame_bgr, int w, int h,
+                                  int blur_radius, float threshold, int morph_closing_size, uint8_t* mask01) {
+  if (!c || !template_bgr || !frame_bgr || !mask01 || w <= 0 || h <= 0 || blur_radius < 0 || blur_radius > 3 ||
+      morph_closing_size < 0 || !(threshold >= 0)) {
+    return fail(c, "bad arguments (blur_radius must be 0..3)");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  DevBuf raw, t4, f4, tb, fb, m0, m1;
+  int rc = 0;
+  if (raw.ensure(n * 6) || t4.ensure(n * 8) || f4.ensure(n * 8) || tb.ensure(n * 8) || fb.ensure(n * 8) || m0.ensure(n) ||
+      m1.ensure(n)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(raw.p, template_bgr, n * 6, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, raw.as<uint16_t>(), t4.as<ushort4>(), n);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipMemcpy(raw.p, frame_bgr, n * 6, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, raw.as<uint16_t>(), f4.as<ushort4>(), n);
+    const ushort4 *tp = t4.as<ushort4>(), *fp = f4.as<ushort4>();
+    if (blur_radius > 0) {
+      hipLaunchKernelGGL(k_gauss_u16, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, t4.as<ushort4>(), tb.as<ushort4>(), w, h, blur_radius);
+      hipLaunchKernelGGL(k_gauss_u16, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, f4.as<ushort4>(), fb.as<ushort4>(), w, h, blur_radius);
+      tp = tb.as<ushort4>();
+      fp = fb.as<ushort4>();
+    }
+    hipLaunchKernelGGL(k_fg_threshold, dim3(flat_grid(n)), dim3(256), 0, c->stream, tp, fp, n, threshold, m0.as<uint8_t>());
+    const uint8_t* res = m0.as<uint8_t>();
+    if (morph_closing_size > 0) {
+      hipLaunchKernelGGL(k_morph_rect, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, m0.as<uint8_t>(), m1.as<uint8_t>(), w, h, morph_closing_size, 1);
+      hipLaunchKernelGGL(k_morph_rect, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, m1.as<uint8_t>(), m0.as<uint8_t>(), w, h, morph_closing_size, 0);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(mask01, res, n, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_generate_foreground_mask: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* b : {&raw, &t4, &f4, &tb, &fb, &m0, &m1}) {
+    b->release();
+  }
+  return rc;
+}
+
 // ---- sibling binaries' kernels, host-pointer convenience forms ----
 int derp_layer_disparities(derp_ctx* c, const float* foreground, const float* background, size_t n, uint8_t* out) {
   if (!c || !foreground || !background || !out) {

@@ -1414,6 +1414,81 @@ __global__ void k_resize_area(const void* __restrict__ src, int SW, int SH, void
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// GenerateForegroundMasks — source/render/BackgroundSubtractionUtil.h:20-60.
+// ----------------------------------------------------------------------------------------
+// cv::GaussianBlur(ksize 2r+1, sigma 0) on CV_16UC3, r in 1..3: fixed small kernels, exact integer
+// products, one round-half-up at the end (OpenCV 4's ufixedpoint32 path); BORDER_REFLECT_101.
+__global__ void k_gauss_u16(const ushort4* __restrict__ in, ushort4* __restrict__ out, int W, int H, int radius) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const int k3[7] = {1, 2, 1, 0, 0, 0, 0}, k5[7] = {1, 4, 6, 4, 1, 0, 0}, k7[7] = {2, 7, 14, 18, 14, 7, 2};
+  const int* k = radius == 1 ? k3 : radius == 2 ? k5 : k7;
+  const int sh = 2 * (radius == 1 ? 2 : radius == 2 ? 4 : 6);
+  unsigned long long acc[3] = {0, 0, 0};
+  for (int j = -radius; j <= radius; ++j) {
+    const int yy = reflect101(y + j, H);
+    unsigned long long row[3] = {0, 0, 0};
+    for (int i = -radius; i <= radius; ++i) {
+      const ushort4 q = in[(size_t)yy * W + reflect101(x + i, W)];
+      const unsigned long long kw = (unsigned long long)k[i + radius];
+      row[0] += kw * q.x;
+      row[1] += kw * q.y;
+      row[2] += kw * q.z;
+    }
+    const unsigned long long kw = (unsigned long long)k[j + radius];
+    acc[0] += kw * row[0];
+    acc[1] += kw * row[1];
+    acc[2] += kw * row[2];
+  }
+  const unsigned long long half = 1ull << (sh - 1);
+  out[(size_t)y * W + x] = make_ushort4((unsigned short)min((acc[0] + half) >> sh, 65535ull),
+                                        (unsigned short)min((acc[1] + half) >> sh, 65535ull),
+                                        (unsigned short)min((acc[2] + half) >> sh, 65535ull), 0);
+}
+// mask = ||template - frame||_2 > threshold on [0,1] floats; cv::norm(Vec3f) sums squares in double
+__global__ void k_fg_threshold(const ushort4* __restrict__ templ, const ushort4* __restrict__ frame, size_t n,
+                               float threshold, uint8_t* __restrict__ mask) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  const float s = 1.0f / 65535.0f;
+  for (; i < n; i += step) {
+    const ushort4 a = templ[i], b = frame[i];
+    const float d0 = fabsf(a.x * s - b.x * s), d1 = fabsf(a.y * s - b.y * s), d2 = fabsf(a.z * s - b.z * s);
+    double acc = 0;
+    acc += (double)d0 * d0;
+    acc += (double)d1 * d1;
+    acc += (double)d2 * d2;
+    mask[i] = sqrt(acc) > (double)threshold;
+  }
+}
+// one pass of cv::dilate / cv::erode with a k x k rectangle anchored at (k/2, k/2); taps outside the image ignored
+__global__ void k_morph_rect(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int W, int H, int k, int dilate) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const int a = k / 2;
+  int v = dilate ? 0 : 1;
+  for (int j = 0; j < k; ++j) {
+    const int yy = y + j - a;
+    if (yy < 0 || yy >= H) {
+      continue;
+    }
+    for (int i = 0; i < k; ++i) {
+      const int xx = x + i - a;
+      if (xx < 0 || xx >= W) {
+        continue;
+      }
+      const int t = in[(size_t)yy * W + xx];
+      v = dilate ? max(v, t) : min(v, t);
+    }
+  }
+  out[(size_t)y * W + x] = (uint8_t)v;
+}
+
 __global__ void k_bgrx_to_bgr(const ushort4* __restrict__ in, uint16_t* __restrict__ out, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;

@@ -39,6 +39,7 @@ EXPORTS = [
     "derp_options_default", "derp_create", "derp_destroy", "derp_last_error", "derp_set_options", "derp_set_pyramid",
     "derp_build_pyramid_color", "derp_build_pyramid_foreground_mask", "derp_build_pyramid_background_disparity",
     "derp_download_level_color", "derp_download_level_mask", "derp_download_level_background", "derp_resize_area",
+    "derp_generate_foreground_mask",
     "derp_upload_color", "derp_upload_foreground_mask", "derp_upload_background_disparity", "derp_upload_disparity",
     "derp_process_level", "derp_process_pyramid", "derp_synchronize", "derp_download_disparity", "derp_download_cost",
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
@@ -221,6 +222,15 @@ class Derp:
         kind = {(np.dtype(np.uint16), 3): 0, (np.dtype(np.uint8), 2): 1, (np.dtype(np.float32), 2): 2}[(src.dtype, src.ndim)]
         out = np.zeros((dh, dw, 3) if kind == 0 else (dh, dw), dtype=src.dtype)
         self._ck(lib().derp_resize_area(self.h, kind, _p(src), src.shape[1], src.shape[0], _p(out), dw, dh))
+        return out
+
+    def generate_foreground_mask(self, template, frame, blur_radius=1, threshold=0.04, morph_closing_size=4):
+        template = np.ascontiguousarray(template, dtype=np.uint16)
+        frame = np.ascontiguousarray(frame, dtype=np.uint16)
+        h, w = frame.shape[:2]
+        out = np.zeros((h, w), dtype=np.uint8)
+        self._ck(lib().derp_generate_foreground_mask(self.h, _p(template), _p(frame), w, h, blur_radius,
+                                                     C.c_float(threshold), morph_closing_size, _p(out)))
         return out
 
     def upload_frame(self, frame):

@@ -106,6 +106,14 @@ int derp_download_level_background(derp_ctx* ctx, int level, int dst, float* dis
 /* one image: kind 0 = BGR u16 x3, 1 = u8 x1, 2 = f32 x1 */
 int derp_resize_area(derp_ctx* ctx, int kind, const void* src, int w, int h, void* dst, int dw, int dh);
 
+/* background_subtraction::generateForegroundMask<Vec3w, Vec3f> for one camera
+ * (source/render/BackgroundSubtractionUtil.h:20-60; GenerateForegroundMasks.cpp:65-130): Gaussian blur
+ * (radius 0..3) of template and frame, ||template - frame||_2 > threshold on [0,1] colours, k x k
+ * morphological close. Both images BGR u16 at the same size; mask01 gets {0,1}. */
+int derp_generate_foreground_mask(derp_ctx* ctx, const uint16_t* template_bgr, const uint16_t* frame_bgr,
+                                  int w, int h, int blur_radius, float threshold,
+                                  int morph_closing_size, uint8_t* mask01);
+
 /* ---- the hot path ------------------------------------------------------------------------ */
 /* One (frame, level): generateFovMasks (DerpUtil.cpp:259-276) + PyramidLevel ctor's
  * computeVariances (PyramidLevel.h:232-247) + precomputeProjections (Derp.cpp:955-976) +

@@ -1086,6 +1086,81 @@ static Img<float> temporalJointBilateralFilter(
   return result;
 }
 
+// ---- source/render/BackgroundSubtractionUtil.h:20-60: generateForegroundMask<Vec3w, Vec3f> ----
+// (the producer of the masks DerpCLI consumes.) OpenCV-defined steps, restated:
+//  * cv::GaussianBlur(ksize 2r+1, sigma 0) on CV_16UC3: sigma <= 0 and ksize <= 7 selects the fixed
+//    small kernels {1,2,1}/4, {1,4,6,4,1}/16, {2,7,14,18,14,7,2}/64; OpenCV 4's 16-bit path is fixed
+//    point (ufixedpoint32), exact products, rounded once half-up; BORDER_REFLECT_101.
+//  * convertTo(CV_32F, 1/65535), cv::absdiff, cv::norm(Vec3f) accumulates squares in double.
+//  * cv::morphologyEx(MORPH_CLOSE, rect k x k, anchor (k/2, k/2)): dilate then erode with the SAME
+//    (unreflected) element, out-of-image taps ignored (morphologyDefaultBorderValue).
+static Img<uint8_t> generateForegroundMask(
+    const Img<Px3w>& templ, const Img<Px3w>& frame, int blurRadius, float threshold, int morphSize) {
+  const int w = templ.w, h = templ.h;
+  auto blur = [&](const Img<Px3w>& in) {
+    if (blurRadius <= 0) {
+      return in;
+    }
+    static const int k3[] = {1, 2, 1}, k5[] = {1, 4, 6, 4, 1}, k7[] = {2, 7, 14, 18, 14, 7, 2};
+    const int* k = blurRadius == 1 ? k3 : blurRadius == 2 ? k5 : k7;
+    const int shift1 = blurRadius == 1 ? 2 : blurRadius == 2 ? 4 : 6;
+    Img<Px3w> out(w, h);
+    for (int y = 0; y < h; ++y) {
+      for (int x = 0; x < w; ++x) {
+        for (int c = 0; c < 3; ++c) {
+          uint64_t acc = 0;
+          for (int j = -blurRadius; j <= blurRadius; ++j) {
+            const int yy = reflect101(y + j, h);
+            uint64_t row = 0;
+            for (int i = -blurRadius; i <= blurRadius; ++i) {
+              row += (uint64_t)k[i + blurRadius] * in.at(yy, reflect101(x + i, w)).c[c];
+            }
+            acc += (uint64_t)k[j + blurRadius] * row;
+          }
+          const int sh = 2 * shift1;
+          out.at(y, x).c[c] = (uint16_t)std::min<uint64_t>(65535, (acc + (1ull << (sh - 1))) >> sh);
+        }
+      }
+    }
+    return out;
+  };
+  const Img<Px3w> tb = blur(templ), fb = blur(frame);
+  Img<uint8_t> mask(w, h, 0);
+  const float s = 1.0f / 65535.0f;
+  for (size_t i = 0; i < mask.d.size(); ++i) {
+    double acc = 0;
+    for (int c = 0; c < 3; ++c) {
+      const float d = std::abs(tb.d[i].c[c] * s - fb.d[i].c[c] * s);
+      acc += (double)d * d;
+    }
+    mask.d[i] = std::sqrt(acc) > threshold;
+  }
+  if (morphSize > 0) {
+    const int a = morphSize / 2;
+    auto pass = [&](const Img<uint8_t>& in, bool dilate) {
+      Img<uint8_t> out(w, h);
+      for (int y = 0; y < h; ++y) {
+        for (int x = 0; x < w; ++x) {
+          uint8_t v = dilate ? 0 : 1;
+          for (int j = 0; j < morphSize; ++j) {
+            for (int i = 0; i < morphSize; ++i) {
+              const int yy = y + j - a, xx = x + i - a;
+              if (yy < 0 || yy >= h || xx < 0 || xx >= w) {
+                continue;
+              }
+              v = dilate ? std::max(v, in.at(yy, xx)) : std::min(v, in.at(yy, xx));
+            }
+          }
+          out.at(y, x) = v;
+        }
+      }
+      return out;
+    };
+    mask = pass(pass(mask, true), false);
+  }
+  return mask;
+}
+
 } // namespace oracle
 
 // =====================================================================
@@ -1512,6 +1587,14 @@ void oracle_cv_variance(const uint16_t* src, int w, int h, float* out) {
   memcpy(s.d.data(), src, size_t(w) * h * 6);
   const Img<float> v = computeImageVariance(s);
   memcpy(out, v.d.data(), size_t(w) * h * 4);
+}
+void oracle_generate_foreground_mask(
+    const uint16_t* templ, const uint16_t* frame, int w, int h, int blurRadius, float threshold, int morphSize, uint8_t* out) {
+  Img<Px3w> t(w, h), f(w, h);
+  memcpy(t.d.data(), templ, size_t(w) * h * 6);
+  memcpy(f.d.data(), frame, size_t(w) * h * 6);
+  const Img<uint8_t> m = generateForegroundMask(t, f, blurRadius, threshold, morphSize);
+  memcpy(out, m.d.data(), size_t(w) * h);
 }
 // pyramid builder: scripts/render/resize.py:51-85 — cv2.resize(full frame, (w, h), INTER_AREA) per level
 void oracle_cv_resize_area_u16c3(const uint16_t* src, int sw, int sh, int dw, int dh, uint16_t* out) {

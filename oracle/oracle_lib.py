@@ -369,6 +369,16 @@ def temporal_filter(guides, images, masks, frame_offset, sigma, radius, w0, w1, 
     return out
 
 
+def generate_foreground_mask(template, frame, blur_radius=1, threshold=0.04, morph_closing_size=4):
+    template = np.ascontiguousarray(template, dtype=np.uint16)
+    frame = np.ascontiguousarray(frame, dtype=np.uint16)
+    h, w = frame.shape[:2]
+    out = np.zeros((h, w), dtype=np.uint8)
+    lib().oracle_generate_foreground_mask(_p(template), _p(frame), w, h, blur_radius, C.c_float(threshold),
+                                          morph_closing_size, _p(out))
+    return out
+
+
 def layer_disparities(fg, bg):
     fg = np.ascontiguousarray(fg, dtype=np.float32)
     bg = np.ascontiguousarray(bg, dtype=np.float32)

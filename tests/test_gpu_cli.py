@@ -231,3 +231,34 @@ def test_resize_module_builds_level_directories(dataset, tmp_path):
         for cam in imgs:
             got = dio.read_png(str(dst / ("level_%d" % level) / cam / "000000.png"))
             assert np.array_equal(got, O.cv_resize_area(imgs[cam], widths[level], widths[level])), (level, cam)
+
+
+def test_generate_foreground_masks_cli(dataset, tmp_path):
+    """GenerateForegroundMasks on full-size frames wider than --width: INTER_AREA downscale, then masks;
+    output PNG 0/255 bit-identical to the oracle chain."""
+    from facebook360_dep_amd import imageio as dio, synth
+    from oracle import oracle_lib as O
+
+    rig = {"cameras": dataset["rig"]["cameras"][:2]}
+    color, bgc = tmp_path / "color", tmp_path / "bgcolor"
+    data = {}
+    rng = np.random.default_rng(17)
+    for cam in rig["cameras"]:
+        bg = synth.render_camera(cam, 192, 192, frame=0)[0]
+        fr = bg.copy()
+        fr[60:120, 40:150] = rng.integers(0, 65536, size=(60, 110, 3))
+        os.makedirs(color / cam["id"])
+        os.makedirs(bgc / cam["id"])
+        dio.write_png16(str(bgc / cam["id"] / "000000.png"), bg)
+        dio.write_png16(str(color / cam["id"] / "000003.png"), fr)
+        data[cam["id"]] = (bg, fr)
+    rigf = tmp_path / "rig.json"
+    rigf.write_text(__import__("json").dumps(rig))
+    out = tmp_path / "masks"
+    run("GenerateForegroundMasks", "--first=000003", "--last=000003", "--rig=" + str(rigf), "--color=" + str(color),
+        "--background_color=" + str(bgc), "--foreground_masks=" + str(out), "--width=96")
+    for cam, (bg, fr) in data.items():
+        ref = O.generate_foreground_mask(O.cv_resize_area(bg, 96, 96), O.cv_resize_area(fr, 96, 96), 1, 0.04, 4)
+        got = dio.read_png(str(out / cam / "000003.png"))
+        assert got.dtype == np.uint8 and np.array_equal(got, ref * 255)
+        assert ref.sum() > 500

@@ -450,3 +450,26 @@ def test_pyramid_builder(built):
         bad, rel = common.compare_disparity(g.download_disparity(0, d), ref[0][d], TOL)
         assert bad == 0, (d, bad, rel)
     g.close()
+
+
+def test_generate_foreground_mask(gpu):
+    """BackgroundSubtractionUtil.h:20-60 — foreground masks must be BIT-EXACT (north star)."""
+    from facebook360_dep_amd import synth
+    from oracle import oracle_lib as O
+
+    rig = synth.make_rig(4, 200)
+    cam = rig["cameras"][1]
+    bg = synth.render_camera(cam, 200, 200, frame=0)[0]
+    rng = np.random.default_rng(6)
+    fr = bg.astype(np.int64) + rng.integers(-600, 600, size=bg.shape)  # sensor noise
+    yy, xx = np.mgrid[0:200, 0:200]
+    blob = ((yy - 90) ** 2 + (xx - 120) ** 2 < 40 ** 2) | ((abs(yy - 30) < 3) & (xx > 20) & (xx < 150))
+    fr[blob] = fr[blob] * 0.5 + 9000  # a foreground object
+    fr = np.clip(fr, 0, 65535).astype(np.uint16)
+    total = 0
+    for blur, thr, morph in ((1, 0.04, 4), (0, 0.04, 0), (2, 0.02, 5), (3, 0.1, 3), (1, 0.0, 1)):
+        ref = O.generate_foreground_mask(bg, fr, blur, thr, morph)
+        got = gpu.generate_foreground_mask(bg, fr, blur, thr, morph)
+        assert np.array_equal(got, ref), (blur, thr, morph, int((got != ref).sum()))
+        total += int(ref.sum())
+    assert 0 < total < 5 * 200 * 200
