@@ -511,8 +511,10 @@ int build_color_tables(derp_ctx* c, int dst0, int nd) {
 
 // number of cost-kernel blocks covering a W x H image (16x16 super-tiles of four 8x8 wave tiles)
 int tiles_of(int W, int H, int& tilesX) {
-  tilesX = (W + 15) / 16;
-  return tilesX * ((H + 15) / 16) * (256 / DERP_COST_BLOCK);
+  constexpr int B = DERP_TILE_BLOCK > 1 ? DERP_TILE_BLOCK : 1;  // tile grid padded to whole B x B squares
+  tilesX = ((W + 15) / 16 + B - 1) / B * B;
+  const int tilesY = ((H + 15) / 16 + B - 1) / B * B;
+  return tilesX * tilesY * (256 / DERP_COST_BLOCK);
 }
 constexpr size_t kCostLdsPerSrc = (size_t)DERP_COST_BLOCK * sizeof(SsdPair);
 int round8(int n) {

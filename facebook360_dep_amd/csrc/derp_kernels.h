@@ -32,6 +32,9 @@ namespace derp {
 #ifndef DERP_COST_BLOCK
 #define DERP_COST_BLOCK 64
 #endif
+#ifndef DERP_TILE_BLOCK
+#define DERP_TILE_BLOCK 4
+#endif
 static constexpr int kPadW = 1;   // ring of projWarp
 static constexpr int kPadC = 2;   // ring of projColor / projBias
 static constexpr int kMaxSrc = 32;
@@ -95,7 +98,17 @@ __device__ __forceinline__ void tile_pixel(int item, int tilesX, int& x, int& y)
   const int lane = threadIdx.x & 63;
   const int gw = item * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
   const int super = gw >> 2, quad = gw & 3;
+#if DERP_TILE_BLOCK > 1
+  // super-tiles are walked in DERP_TILE_BLOCK x DERP_TILE_BLOCK squares (128 x 128 px for 8): the tiles an
+  // XCD works on at one time then cover a compact square instead of a 16-px-high strip, which shrinks
+  // the union of the source-image footprints their gathers fall into (tilesX is padded to the block size)
+  constexpr int B = DERP_TILE_BLOCK;
+  const int blk = super / (B * B), in = super % (B * B);
+  const int blocksX = tilesX / B;
+  const int tx = (blk % blocksX) * B + (in % B), ty = (blk / blocksX) * B + (in / B);
+#else
   const int tx = super % tilesX, ty = super / tilesX;
+#endif
   x = tx * 16 + (quad & 1) * 8 + (lane & 7);
   y = ty * 16 + (quad >> 1) * 8 + (lane >> 3);
 }
