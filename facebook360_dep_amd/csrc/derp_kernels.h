@@ -1162,7 +1162,17 @@ __global__ void __launch_bounds__(256)
   out[(size_t)p * planeStride + (size_t)y * W + x] = result;
 }
 
-// maskedMedianBlur radius 1 — CvUtil.h:336-385; optional fused maskFov (Derp.cpp:940-951)
+// maskedMedianBlur — CvUtil.h:336-385; optional fused maskFov (Derp.cpp:940-951).
+// Median of the taps that are in bounds, inside the mask, not NaN and not 0; even count -> mean of
+// the two middle values (in double, as the reference's "/ 2.0"). Radius 1 (the value DerpCLI uses,
+// Derp.h:36) keeps the 9 candidates in registers and orders them with a 25-exchange sorting network,
+// invalid taps as +inf; the result depends only on the multiset of values, not on the sort used.
+__device__ __forceinline__ void cswap(float& a, float& b) {
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+
 __global__ void k_masked_median(const float* __restrict__ image, const float* __restrict__ background,
                                 const uint8_t* __restrict__ mask, int W, int H, int radius, float* __restrict__ out,
                                 size_t planeStride, const uint8_t* __restrict__ fovForNan) {
@@ -1178,6 +1188,47 @@ __global__ void k_masked_median(const float* __restrict__ image, const float* __
   if (!m[idx]) {
     if (background) {
       result = background[(size_t)p * planeStride + idx];
+    }
+  } else if (radius == 1) {
+    const float inf = __builtin_inff();
+    float v[9];
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int yy = y + j - 1, xx = x + i - 1;
+        float t = inf;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+          const size_t q = (size_t)yy * W + xx;
+          const float val = img[q];
+          if (m[q] && !isnan(val) && val != 0) {
+            t = val;
+            ++cnt;
+          }
+        }
+        v[j * 3 + i] = t;
+      }
+    }
+    // 9-input sorting network (25 compare-exchanges)
+    cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[1], v[2]); cswap(v[4], v[5]); cswap(v[7], v[8]);
+    cswap(v[0], v[1]); cswap(v[3], v[4]); cswap(v[6], v[7]);
+    cswap(v[0], v[3]); cswap(v[3], v[6]); cswap(v[0], v[3]);
+    cswap(v[1], v[4]); cswap(v[4], v[7]); cswap(v[1], v[4]);
+    cswap(v[2], v[5]); cswap(v[5], v[8]); cswap(v[2], v[5]);
+    cswap(v[1], v[3]); cswap(v[5], v[7]); cswap(v[2], v[6]);
+    cswap(v[4], v[6]); cswap(v[2], v[4]); cswap(v[2], v[3]);
+    cswap(v[5], v[6]);
+    if (cnt > 0) {
+      const int h = cnt / 2;
+      float lo = v[0], hi = v[0];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {  // v[h - 1], v[h] without dynamic register indexing
+        lo = (k == h - 1) ? v[k] : lo;
+        hi = (k == h) ? v[k] : hi;
+      }
+      result = (cnt & 1) ? hi : (float)(((double)(lo + hi)) / 2.0);
     }
   } else {
     float vals[25];
@@ -1195,7 +1246,6 @@ __global__ void k_masked_median(const float* __restrict__ image, const float* __
         if (isnan(v) || v == 0) {
           continue;
         }
-        // insertion into sorted order (values only: the median does not depend on the sort used)
         int k = cnt++;
         while (k > 0 && vals[k - 1] > v) {
           vals[k] = vals[k - 1];
