@@ -254,6 +254,7 @@ def main():
             "algorithmic_bytes_per_launch": alg_bytes,
             "n_cost_per_launch": pp["n_cost"] / launches,
             "n_pair_per_launch": pp["n_pair"] / launches,
+            "memoised_cost_evals_per_launch": g.profile_memoised("ping_pong", 0) / launches,
             "whole_step_algorithmic_GBps": round(whole_alg / (dt / args.steps) / 1e9, 1),
             "whole_step_frac_of_peak": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
         },

@@ -109,9 +109,10 @@ struct derp_ctx {
   // working level
   int cur = -1;
   int DB = 0;  // dst batch that fits the table budget
-  DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask;
+  DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask, pairCount;
   DevBuf projWarp, projColor, projBias, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
   int warpCachedLevel = -1;
+  bool randomRanThisLevel = false;  // cost / confidence hold random-proposal results for this level
   bool tablesValid = false;
   DevBuf counters;  // [ST_COUNT][kMaxLevels][4] u64
   std::map<std::pair<int, int>, LanczosTab*> lanczos;
@@ -239,6 +240,7 @@ LevelView make_view(derp_ctx* c, int stage, int dst0, int nd) {
   V.confidence = c->confidence.as<float>();
   V.bgDisp = c->pyrBg[L].as<float>();
   V.fovMask = c->fovMask.as<uint8_t>();
+  V.pairCount = c->pairCount.as<uint8_t>();
   V.counters = counter_slot(c, stage, L);
   return V;
 }
@@ -551,6 +553,7 @@ int run_random_proposals(derp_ctx* c, int dst0, int nd) {
     return 0;
   }
   Span sp(c, ST_RANDOM, L);
+  c->randomRanThisLevel = true;
   LevelView V = make_view(c, ST_RANDOM, dst0, nd);
   if (V.H > 2 && V.W > 2) {
     hipLaunchKernelGGL(k_row_rank, dim3(V.H - 2, nd), dim3(256), 0, c->stream, V, c->rank.as<int>());
@@ -579,7 +582,8 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
   for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
     hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->changed.as<uint8_t>(),
-                       c->dispRes.as<float>(), c->costRes.as<float>(), tilesX, tiles);
+                       c->dispRes.as<float>(), c->costRes.as<float>(), tilesX,
+                       (int)(it == 1 && c->randomRanThisLevel && !getenv("DERP_NO_MEMO")));
     KCHECK(c);
     hipLaunchKernelGGL(k_ping_pong_commit, dim3(flat_grid(n * nd)), dim3(256), 0, c->stream,
                        c->disparity.as<float>() + (size_t)dst0 * n, c->cost.as<float>() + (size_t)dst0 * n,
@@ -755,6 +759,7 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   ALLOC(c, c->projColor, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
   ALLOC(c, c->projBias, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
   c->tablesValid = false;
+  c->randomRanThisLevel = false;
   if (buildAllTables) {
     if (DB < c->D) {
       return fail(c, "stage-level API needs all destinations' tables resident (batch %d < %d)", DB, c->D);
@@ -932,7 +937,7 @@ void derp_destroy(derp_ctx* c) {
     }
   }
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
-                    &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask,
+                    &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
                     &c->projWarp, &c->projColor, &c->projBias, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
@@ -1011,6 +1016,7 @@ int derp_set_pyramid(derp_ctx* c, int num_levels, const int* widths, const int* 
   }
   ALLOC(c, c->changed, nmax * c->D);
   ALLOC(c, c->mismatchMask, nmax * c->D);
+  ALLOC(c, c->pairCount, nmax * c->D);
   c->cur = -1;
   c->warpCachedLevel = -1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1192,6 +1198,7 @@ int derp_set_level_disparity(derp_ctx* c, int d, const float* disp) {
   const size_t n = npx(c, c->cur);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(c->disparity.as<float>() + (size_t)d * n, disp, n * sizeof(float), hipMemcpyHostToDevice));
+  c->randomRanThisLevel = false;  // cost[] no longer belongs to the working disparity
   return 0;
 }
 int derp_get_level_disparity(derp_ctx* c, int d, float* disp) {
@@ -1820,6 +1827,31 @@ int derp_profile_query(derp_ctx* c, const char* stage, int level, double* ms, in
   if (n_pair) {
     *n_pair = b;
   }
+  return 0;
+}
+int derp_profile_memoised(derp_ctx* c, const char* stage, int level, uint64_t* n_memoised) {
+  if (!c || !stage || !n_memoised) {
+    return 1;
+  }
+  int st = -1;
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (strcmp(stage, kStageNames[i]) == 0) {
+      st = i;
+    }
+  }
+  if (st < 0) {
+    return fail(c, "unknown stage '%s'", stage);
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::vector<unsigned long long> h((size_t)kMaxLevels * 4);
+  HIPCHK(c, hipMemcpy(h.data(), counter_slot(c, st, 0), h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  uint64_t m = 0;
+  for (int lv = 0; lv < kMaxLevels; ++lv) {
+    if (level < 0 || lv == level) {
+      m += h[(size_t)lv * 4 + 3];
+    }
+  }
+  *n_memoised = m;
   return 0;
 }
 int derp_device_name(derp_ctx* c, char* buf, int n) {

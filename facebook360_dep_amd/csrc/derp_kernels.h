@@ -69,7 +69,8 @@ struct LevelView {
   float* confidence;
   const float* bgDisp;        // [Dtotal][H*W] or null
   const uint8_t* fovMask;     // [Dtotal][H*W]
-  unsigned long long* counters;  // [0] nCost [1] nPair [2] insufficient coverage [3] check failed
+  uint8_t* pairCount;            // [Dtotal][H*W] #pairs behind cost[] where random proposals evaluated the pixel
+  unsigned long long* counters;  // [0] nCost [1] nPair [2] insufficient coverage [3] cost evaluations served from memo
 };
 
 __device__ __forceinline__ size_t warp_plane(const LevelView& V) {
@@ -801,8 +802,10 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
         PixCtx px;
         load_pixctx(V, d, own, x, y, px);
         float currDisp = disp[idx];
+        unsigned before = nPair;
         float2 cur = compute_cost(V, dl, own, px, currDisp, pairs, nPair);
         ++nCost;
+        unsigned currPairs = nPair - before;
         float currCost = cur.x, currConf = cur.y;
         const float costThresh = fminf(0.5f * currCost, 5.0f);  // kRandomPropMaxCost
         const float minDisp = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : (1.0f / V.maxDepthM);
@@ -813,18 +816,21 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
         for (int i = 0; i < V.randomProposals; ++i) {
           const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
           const float propDisp = minstd_uniform(state, lo, hi);
+          before = nPair;
           const float2 pr = compute_cost(V, dl, own, px, propDisp, pairs, nPair);
           ++nCost;
           if (pr.x < currCost && pr.x < costThresh) {
             currCost = pr.x;
             currDisp = propDisp;
             currConf = pr.y;
+            currPairs = nPair - before;
             amplitude /= 2.0f;
           }
         }
         disp[idx] = currDisp;
         V.cost[(size_t)d * n + idx] = currCost;
         V.confidence[(size_t)d * n + idx] = currConf;
+        V.pairCount[(size_t)d * n + idx] = (uint8_t)currPairs;
       }
     }
   }
@@ -838,14 +844,14 @@ __constant__ int kCandidates[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, 
 
 __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     k_ping_pong(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
-                float* __restrict__ costRes, int tilesX, int tilesPerDst) {
+                float* __restrict__ costRes, int tilesX, int useMemo) {
   extern __shared__ SsdPair ldsPairs[];
   const int dl = blockIdx.y;
   const int d = V.dst0 + dl;
   int x, y;
   tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x), tilesX, x, y);
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
-  unsigned nCost = 0, nPair = 0;
+  unsigned nCost = 0, nPair = 0, nMemo = 0;
   if (x < V.W && y < V.H) {
     const int own = V.dst2src[d];
     const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
@@ -870,7 +876,17 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
           if (fov[j]) {
             const float cand = disp[j];
             if (cand >= bg && changed[(size_t)d * n + j]) {
-              const float2 r = compute_cost(V, dl, own, px, cand, pairs, nPair);
+              float2 r;
+              // Candidate (0,0) is the pixel's own disparity. In the first iteration, where random
+              // proposals evaluated this pixel, computeCost(own disparity) is exactly the value they
+              // left in cost / confidence (a pure function of the same arguments): reuse it.
+              if (k == 0 && useMemo && V.confidence[(size_t)d * n + idx] != 0.0f) {
+                r = make_float2(V.cost[(size_t)d * n + idx], V.confidence[(size_t)d * n + idx]);
+                nPair += V.pairCount[(size_t)d * n + idx];
+                ++nMemo;
+              } else {
+                r = compute_cost(V, dl, own, px, cand, pairs, nPair);
+              }
               ++nCost;
               if (r.x < bestCost) {
                 bestCost = r.x;
@@ -887,6 +903,12 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     costRes[(size_t)d * n + idx] = outCost;
   }
   flush_counters(V, nCost, nPair);
+  for (int off = 32; off > 0; off >>= 1) {
+    nMemo += __shfl_down(nMemo, off);
+  }
+  if ((threadIdx.x & 63) == 0 && nMemo) {
+    atomicAdd(&V.counters[3], (unsigned long long)nMemo);
+  }
 }
 
 // changed = disp != dispRes; dispRes -> disp; costRes -> cost (Derp.cpp:527-529)

@@ -47,7 +47,7 @@ EXPORTS = [
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
     "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
-    "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query",
+    "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
     "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
 ]
 
@@ -427,6 +427,11 @@ class Derp:
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(lib().derp_profile_query(self.h, stage.encode(), level, C.byref(ms), C.byref(n), C.byref(a), C.byref(b)))
         return dict(ms=ms.value, launches=n.value, n_cost=a.value, n_pair=b.value)
+
+    def profile_memoised(self, stage, level=-1):
+        m = C.c_uint64()
+        self._ck(lib().derp_profile_memoised(self.h, stage.encode(), level, C.byref(m)))
+        return m.value
 
     def device_name(self):
         buf = C.create_string_buffer(256)

@@ -204,6 +204,10 @@ int derp_profile_enable(derp_ctx* ctx, int on);
 int derp_profile_reset(derp_ctx* ctx);
 int derp_profile_query(derp_ctx* ctx, const char* stage, int level, double* ms, int* launches,
                        uint64_t* n_cost, uint64_t* n_pair);
+/* computeCost evaluations of `stage` / `level` that were served from an earlier identical evaluation
+ * instead of being recomputed (first ping-pong iteration, candidate (0,0)); they ARE included in the
+ * logical n_cost / n_pair above, which count what the reference algorithm issues. */
+int derp_profile_memoised(derp_ctx* ctx, const char* stage, int level, uint64_t* n_memoised);
 int derp_device_name(derp_ctx* ctx, char* buf, int n);
 
 /* host-only self checks (no GPU needed): restated libstdc++ algorithms the device code uses */
