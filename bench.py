@@ -222,7 +222,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 photometry + f64 geometry over u16 texels",
+        "dtype": "f32",  # photometry in f32 over u16 texels; camera geometry in f64
         "data": "synthetic",
         "config": {
             "workload": ("%s: %d-camera %dx%d synthetic rig, single frame, full %d-level pyramid"

@@ -473,3 +473,112 @@ def test_generate_foreground_mask(gpu):
         assert np.array_equal(got, ref), (blur, thr, morph, int((got != ref).sum()))
         total += int(ref.sum())
     assert 0 < total < 5 * 200 * 200
+
+
+def test_reference_test_rig_non_square(built):
+    """The reference's own 16-camera test rig (res/test/rigs/rig.json: real calibration, 3360x2160,
+    off-centre principal points, 3-term distortion, rotation matrices that need re-unitarising) on
+    non-square pyramid levels (200x130, 128x82, 100x64 — resize.py's even-height rule)."""
+    import json
+    import os
+
+    from facebook360_dep_amd import derp, synth
+
+    rig = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_test_rig.json")))
+    sizes = synth.level_sizes(3360, 2160, [200, 128, 100])
+    assert sizes == [(200, 130), (128, 82), (100, 64)]
+    frame = synth.make_frame(rig, sizes)
+    cnt = {}
+    ref = common.oracle_pyramid(rig, sizes, frame, 3360, 2160, counters=cnt, partial_coverage=True)
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid(sizes, 3360, 2160)
+    g.upload_frame(frame)
+    g.process_pyramid()
+    g.synchronize()
+    nbad = npx = 0
+    for level in ref:
+        for d in range(16):
+            got = g.download_disparity(level, d)
+            assert got.shape == (sizes[level][1], sizes[level][0])
+            bad, rel = common.compare_disparity(got, ref[level][d], TOL)
+            nbad += bad
+            npx += got.size
+    print("reference test rig: %d of %d pixels outside 1e-4" % (nbad, npx))
+    assert nbad <= 1e-4 * npx
+    assert g.counters()["n_cost"] == sum(c["n_cost"] for c in cnt.values())
+    # the subset / reorder path on the same rig (DerpTest.cpp's "cam4,cam15,cam0")
+    sub = derp.filter_destinations(rig["cameras"], "cam4,cam15,cam0")
+    g2 = derp.Derp(rig["cameras"], sub, partial_coverage=1)
+    g2.set_pyramid(sizes, 3360, 2160)
+    g2.upload_frame(frame)
+    g2.process_pyramid()
+    g2.synchronize()
+    for k, d in enumerate((4, 15, 0)):
+        assert _float_equal(g2.download_disparity(0, k), g.download_disparity(0, d)) == 0
+    g.close()
+    g2.close()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(ping_pong_iterations=2),
+    dict(random_proposals=0),
+    dict(random_proposals=5, ping_pong_iterations=3),
+    dict(do_bilateral_filter=False, do_median_filter=False),
+    dict(min_depth_m=1.0, max_depth_m=50.0, var_noise_floor=1e-3, var_high_thresh=5e-2),
+    dict(mismatches_start_level=2, ping_pong_iterations=2),
+])
+def test_option_matrix(small, opts):
+    """DerpCLI flags that change the schedule (DerpCLI.cpp:44-67), each against the oracle."""
+    stats = _run_pyramid(small, partial_coverage=True, **opts)
+    for level, (bad, npx, worst) in stats.items():
+        assert bad <= 1e-4 * npx, (opts, level, bad, npx, worst)
+
+
+def test_edge_cases(built):
+    """Degenerate inputs: tiny ragged levels, an all-background camera, an all-foreground-but-empty
+    mask, constant (zero-variance) imagery, and a single-level pyramid."""
+    from facebook360_dep_amd import derp, synth
+
+    rig = synth.make_rig(4, 64)
+    sizes = [(64, 64), (24, 18), (7, 5)]  # ragged, odd, and a level whose interior is 5 x 3 pixels
+    frame = synth.make_frame(rig, [(64, 64)], with_masks=True)
+    color = [[synth.resize_area(frame["color"][0][s].astype(np.float64), w, h).round().astype(np.uint16)
+              for s in range(4)] for (w, h) in sizes]
+    masks = [[(synth.resize_area(frame["masks"][0][s] * 255.0, w, h) > 127).astype(np.uint8) for s in range(4)]
+             for (w, h) in sizes]
+    bgd = [[synth.resize_area(frame["bg_disp"][0][s], w, h).astype(np.float32) for s in range(4)] for (w, h) in sizes]
+    for lvl in range(3):
+        masks[lvl][1][:] = 0                       # camera 1: everything is background
+        color[lvl][2][:] = 31000                   # camera 2: constant image, zero variance everywhere
+    fr = {"color": color, "masks": masks, "bg_disp": bgd}
+    for use_fg in (False, True):
+        ref = common.oracle_pyramid(rig, sizes, fr, 64, 64, partial_coverage=True, use_foreground_masks=use_fg)
+        g = derp.Derp(rig["cameras"], partial_coverage=1, use_foreground_masks=int(use_fg))
+        g.set_pyramid(sizes, 64, 64)
+        g.upload_frame(fr if use_fg else {"color": color})
+        g.process_pyramid()
+        g.synchronize()
+        for level in ref:
+            for d in range(4):
+                bad, rel = common.compare_disparity(g.download_disparity(level, d), ref[level][d], TOL)
+                assert bad == 0, (use_fg, level, d, bad, rel)
+        if use_fg:  # the all-background camera reproduces its background disparity inside the FOV
+            got = g.download_disparity(0, 1)
+            fov = g.fov_mask(1, 64, 64) == 1
+            assert np.array_equal(got[fov], bgd[0][1][fov])
+        g.close()
+    # single-level pyramid: brute force + filters only
+    ref = common.oracle_pyramid(rig, [(64, 64)], {"color": [color[0]]}, 64, 64, partial_coverage=True)
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid([(64, 64)], 64, 64)
+    g.upload_frame({"color": [color[0]]})
+    g.process_pyramid()
+    g.synchronize()
+    for d in range(4):
+        assert common.compare_disparity(g.download_disparity(0, d), ref[0][d], TOL)[0] == 0
+    # API misuse is an error code + message, never a crash
+    with pytest.raises(derp.DerpError):
+        g.process_level(3)
+    with pytest.raises(derp.DerpError):
+        g.set_options(random_proposals=-1)
+    g.close()
