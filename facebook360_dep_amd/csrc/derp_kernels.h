@@ -190,44 +190,66 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
   float first = 0.f, second = 0.f;
   const bool regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
   if (regular) {
-    // 4x4 texel block rows yi[1]-2 .. yi[1]+1, cols xi[1]-2 .. xi[1]+1
-    float t[4][4][3];
+    // 4x4 texel block rows yi[1]-2 .. yi[1]+1, cols xi[1]-2 .. xi[1]+1, streamed two rows at a time:
+    // offset row iy needs texel rows iy and iy+1 only, so at most two converted rows are live (the
+    // per-offset sums are parked and added in the reference's dx-outer / dy-inner order afterwards).
     const ushort4* r = col + (size_t)(yi[1] - 2 + kPadC) * pitch + (xi[1] - 2 + kPadC);
+    u4a8 raw[4][2];
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
-      const u4a8 a = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
-      const u4a8 b = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
-      t[row][0][0] = (float)(a.x & 0xffff);
-      t[row][0][1] = (float)(a.x >> 16);
-      t[row][0][2] = (float)(a.y & 0xffff);
-      t[row][1][0] = (float)(a.z & 0xffff);
-      t[row][1][1] = (float)(a.z >> 16);
-      t[row][1][2] = (float)(a.w & 0xffff);
-      t[row][2][0] = (float)(b.x & 0xffff);
-      t[row][2][1] = (float)(b.x >> 16);
-      t[row][2][2] = (float)(b.y & 0xffff);
-      t[row][3][0] = (float)(b.z & 0xffff);
-      t[row][3][1] = (float)(b.z >> 16);
-      t[row][3][2] = (float)(b.w & 0xffff);
+      raw[row][0] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
+      raw[row][1] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
     }
+    float d0s[3][3], d1s[3][3];  // [ix][iy]
+    float lo[4][3], hi[4][3];    // converted texel rows iy and iy + 1
+    auto unpack = [](const u4a8& a, const u4a8& b, float (&t)[4][3]) {
+      t[0][0] = (float)(a.x & 0xffff);
+      t[0][1] = (float)(a.x >> 16);
+      t[0][2] = (float)(a.y & 0xffff);
+      t[1][0] = (float)(a.z & 0xffff);
+      t[1][1] = (float)(a.z >> 16);
+      t[1][2] = (float)(a.w & 0xffff);
+      t[2][0] = (float)(b.x & 0xffff);
+      t[2][1] = (float)(b.x >> 16);
+      t[2][2] = (float)(b.y & 0xffff);
+      t[3][0] = (float)(b.z & 0xffff);
+      t[3][1] = (float)(b.z >> 16);
+      t[3][2] = (float)(b.w & 0xffff);
+    };
+    unpack(raw[0][0], raw[0][1], lo);
 #pragma unroll
-    for (int ix = 0; ix < 3; ++ix) {
+    for (int iy = 0; iy < 3; ++iy) {
+      unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
 #pragma unroll
-      for (int iy = 0; iy < 3; ++iy) {
+      for (int ix = 0; ix < 3; ++ix) {
         const float w00 = (1 - xw[ix]) * (1 - yw[iy]), w01 = xw[ix] * (1 - yw[iy]);
         const float w10 = (1 - xw[ix]) * yw[iy], w11 = xw[ix] * yw[iy];
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float cs = bilerp_u16(t[iy][ix][c], t[iy][ix + 1][c], t[iy + 1][ix][c], t[iy + 1][ix + 1][c], w00,
-                                      w01, w10, w11);
+          const float cs = bilerp_u16(lo[ix][c], lo[ix + 1][c], hi[ix][c], hi[ix + 1][c], w00, w01, w10, w11);
           const float db = px.patch[ix * 3 + iy][c] - cs;
           const float dn = db - bias[c];
           d0 += db * db;
           d1 += dn * dn;
         }
-        first += d0;
-        second += d1;
+        d0s[ix][iy] = d0;
+        d1s[ix][iy] = d1;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          lo[k][c] = hi[k][c];
+        }
+      }
+    }
+#pragma unroll
+    for (int ix = 0; ix < 3; ++ix) {
+#pragma unroll
+      for (int iy = 0; iy < 3; ++iy) {
+        first += d0s[ix][iy];
+        second += d1s[ix][iy];
       }
     }
   } else {
