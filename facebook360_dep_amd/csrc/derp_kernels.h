@@ -1087,6 +1087,15 @@ __constant__ unsigned long long kExp2fTab[32] = {
     0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull,
     0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full, 0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
 
+// Correctly rounded fp32 quotient by a constant without the fp32 divide sequence: for floats y, d the
+// product RN64(y * RN64(1/d)) carries a relative error <= 2^-52, while y/d can come no closer than
+// 2^-49 (relative) to a rounding boundary of fp32 unless it sits exactly on a representable value
+// (y - m*d is a non-zero multiple of the 49-bit product's last bit for every 25-bit midpoint m), so
+// rounding the double product to float gives exactly the IEEE result of y / d. `rcp` = 1.0 / (double)d.
+__device__ __forceinline__ float div_by_const(float y, double rcp) {
+  return (float)((double)y * rcp);
+}
+
 // `tab` = kExp2fTab staged in LDS by the caller (a divergent __constant__ index would be a global load per call)
 __device__ __forceinline__ float expf_glibc(float x, const unsigned long long* tab) {
   const double InvLn2N = 0x1.71547652b82fep+0 * 32;
@@ -1184,6 +1193,7 @@ __global__ void __launch_bounds__(256)
   if (tMask[c]) {
     const float g0 = tG0[c], g1 = tG1[c], g2 = tG2[c];
     const float denom = 2.0f * (sigma * sigma);
+    const double rcpDenom = 1.0 / (double)denom, rcp3 = 1.0 / 3.0;
     float sumWeight = 0.f, weightedAvg = 0.f;
     for (int v = -radius; v <= radius; ++v) {
       const int row = c + v * T;
@@ -1194,7 +1204,7 @@ __global__ void __launch_bounds__(256)
         }
         const float d0 = g0 - tG0[j], d1 = g1 - tG1[j], d2 = g2 - tG2[j];
         const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
-        const float weight = expf_glibc((-colorDiffSq / 3.0f) / denom, expTab);
+        const float weight = expf_glibc(div_by_const(div_by_const(-colorDiffSq, rcp3), rcpDenom), expTab);  // (-c / 3.0f) / denom
         sumWeight += weight;
         weightedAvg += weight * tImg[j];
       }
@@ -1638,6 +1648,7 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
   }
   const ushort4 ref = F.guides[frameOffset][idx];
   const float sig2 = sigma * sigma;
+  const double rcpSig2 = 1.0 / (double)sig2;
   float weightedSumPix = 0.f, sumWeight = 0.f;
   for (int t = 0; t < F.n; ++t) {
     const float centre = F.images[t][idx];
@@ -1654,7 +1665,7 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
         const float e1 = (float)((int)ref.y - (int)sc.y) / 65535.0f;
         const float e2 = (float)((int)ref.z - (int)sc.z) / 65535.0f;
         const float weightedDiff = weight0 * (e0 * e0) + weight1 * (e1 * e1) + weight2 * (e2 * e2);
-        const float weight = expf_glibc(-weightedDiff / sig2, expTab);
+        const float weight = expf_glibc(div_by_const(-weightedDiff, rcpSig2), expTab);  // -weightedDiff / sig2
         weightedSumPix += centre * weight;
         sumWeight += weight;
       }
