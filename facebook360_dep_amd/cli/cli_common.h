@@ -28,13 +28,25 @@ namespace cli {
 namespace fs = std::filesystem;
 
 // ---------------------------------------------------------------- logging (glog look-alike)
+// --log_dir=<dir>: every line also goes to <dir>/<program>.INFO, the name glog's symlink has and the
+// reference's tests read back (scripts/test/test_derp_cli.py:50-62)
+inline FILE*& log_file() {
+  static FILE* f = nullptr;
+  return f;
+}
 inline void vlog(char sev, const char* file, int line, const std::string& msg) {
   time_t t = time(nullptr);
   struct tm tmv;
   localtime_r(&t, &tmv);
   const char* base = strrchr(file, '/');
-  fprintf(stderr, "%c%02d%02d %02d:%02d:%02d %s:%d] %s\n", sev, tmv.tm_mon + 1, tmv.tm_mday, tmv.tm_hour, tmv.tm_min,
-          tmv.tm_sec, base ? base + 1 : file, line, msg.c_str());
+  char head[256];
+  snprintf(head, sizeof head, "%c%02d%02d %02d:%02d:%02d %s:%d] ", sev, tmv.tm_mon + 1, tmv.tm_mday, tmv.tm_hour,
+           tmv.tm_min, tmv.tm_sec, base ? base + 1 : file, line);
+  fprintf(stderr, "%s%s\n", head, msg.c_str());
+  if (log_file()) {
+    fprintf(log_file(), "%s%s\n", head, msg.c_str());
+    fflush(log_file());
+  }
 }
 #define LOG_INFO(msg) cli::vlog('I', __FILE__, __LINE__, (msg))
 #define LOG_WARNING(msg) cli::vlog('W', __FILE__, __LINE__, (msg))
@@ -197,8 +209,8 @@ struct Flags {
     }
   }
   void parse(int argc, char** argv) {
-    // glog flags the pipeline passes (res/flags/*.flags): accepted, logging always goes to stderr
-    str("log_dir", "", "glog: directory for log files (accepted; logs go to stderr)");
+    // glog flags the pipeline passes (res/flags/*.flags); logging always goes to stderr as well
+    str("log_dir", "", "glog: directory for <program>.INFO");
     boolean("alsologtostderr", false, "glog: accepted");
     boolean("logtostderr", false, "glog: accepted");
     i32("stderrthreshold", 2, "glog: accepted");
@@ -206,6 +218,12 @@ struct Flags {
     i32("minloglevel", 0, "glog: accepted");
     std::vector<std::string> toks(argv + 1, argv + argc);
     parse_tokens(toks, false);
+    if (!s("log_dir").empty()) {
+      std::error_code ec;
+      std::filesystem::create_directories(s("log_dir"), ec);
+      const std::string prog = std::filesystem::path(argv[0]).filename().string();
+      log_file() = fopen((std::filesystem::path(s("log_dir")) / (prog + ".INFO")).c_str(), "w");
+    }
     // SystemUtil.cpp:78-97: log every project flag at start
     for (const auto& n : order) {
       LOG_INFO("--" + n + "=" + defs.at(n).value);

@@ -1451,6 +1451,137 @@ int derp_layer_disparities(derp_ctx* c, const float* foreground, const float* ba
   }
   return rc;
 }
+// ---- rephotography score (RephotographyUtil.h:38-116, ComputeRephotographyErrors.cpp:69-189) ----
+int derp_ssim(derp_ctx* c, const float* x_bgr, const float* y_bgr, int w, int h, int blur_radius, float alpha,
+              float beta, float gamma, float* score_bgr) {
+  auto is01 = [](float v) { return v == 0.0f || v == 1.0f; };
+  if (!c || !x_bgr || !y_bgr || !score_bgr || w <= 0 || h <= 0 || blur_radius < 1 || blur_radius > 15) {
+    return fail(c, "bad arguments (blur_radius must be 1..15)");
+  }
+  if (!is01(alpha) || !is01(beta) || !is01(gamma)) {
+    return fail(c, "exponents other than 0 and 1 are not supported (computeScoreMap uses MSSIM = 1,1,1 / NCC = 0,0,1)");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  // getGaussianKernel(2r + 1, 1.5, CV_32F): OpenCV 4's order of operations, in double, rounded to float
+  GaussCoef coef{};
+  {
+    const int n = 2 * blur_radius + 1;
+    const double sigma = 1.5f, scale2X = -0.125 / (sigma * sigma);
+    double t[16], sum = 0;
+    for (int i = 0, x = 1 - n; i < blur_radius; ++i, x += 2) {
+      t[i] = std::exp((double)(x * x) * scale2X);
+      sum += t[i];
+    }
+    sum *= 2;
+    sum += 1;
+    const double mul = 1.0 / sum;
+    coef.k[0] = (float)mul;
+    for (int i = 0; i < blur_radius; ++i) {
+      coef.k[blur_radius - i] = (float)(t[i] * mul);
+    }
+  }
+  const size_t n3 = (size_t)w * h * 3, bytes = n3 * 4;
+  DevBuf x, y, muX, muY, a, b, cc, tmp, s2x, s2y, sxy;
+  int rc = 0;
+  bool oom = false;
+  for (DevBuf* buf : {&x, &y, &muX, &muY, &a, &b, &cc, &tmp, &s2x, &s2y, &sxy}) {
+    oom = oom || buf->ensure(bytes);
+  }
+  if (oom) {
+    rc = fail(c, "out of device memory");
+  } else {
+    (void)hipMemcpy(x.p, x_bgr, bytes, hipMemcpyHostToDevice);
+    (void)hipMemcpy(y.p, y_bgr, bytes, hipMemcpyHostToDevice);
+    const dim3 grid = grid2d(w * 3, h, 1, kBlk2d);
+    auto blur = [&](const DevBuf& in, DevBuf& out) {
+      hipLaunchKernelGGL(k_gauss_f32c3, grid, kBlk2d, 0, c->stream, in.as<float>(), tmp.as<float>(), w, h, blur_radius, coef, 0);
+      hipLaunchKernelGGL(k_gauss_f32c3, grid, kBlk2d, 0, c->stream, tmp.as<float>(), out.as<float>(), w, h, blur_radius, coef, 1);
+    };
+    blur(x, muX);
+    blur(y, muY);
+    hipLaunchKernelGGL(k_ssim_moments, dim3(flat_grid(n3)), dim3(256), 0, c->stream, x.as<float>(), y.as<float>(),
+                       muX.as<float>(), muY.as<float>(), a.as<float>(), b.as<float>(), cc.as<float>(), n3);
+    blur(a, s2x);
+    blur(b, s2y);
+    blur(cc, sxy);
+    // the score overwrites `a`
+    hipLaunchKernelGGL(k_ssim_score, dim3(flat_grid(n3)), dim3(256), 0, c->stream, muX.as<float>(), muY.as<float>(),
+                       s2x.as<float>(), s2y.as<float>(), sxy.as<float>(), alpha != 0.0f, beta != 0.0f, gamma != 0.0f,
+                       a.as<float>(), n3);
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(score_bgr, a.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_ssim: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* buf : {&x, &y, &muX, &muY, &a, &b, &cc, &tmp, &s2x, &s2y, &sxy}) {
+    buf->release();
+  }
+  return rc;
+}
+
+int derp_average_score(const float* score_bgr, const uint8_t* mask, int w, int h, double* avg_bgr3) {
+  if (!score_bgr || !mask || !avg_bgr3 || w <= 0 || h <= 0) {
+    return 1;
+  }
+  const size_t n = (size_t)w * h;
+  for (int ch = 0; ch < 3; ++ch) {
+    double sum = 0;
+    size_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) {
+      const float v = score_bgr[i * 3 + ch];
+      if (mask[i] && !std::isnan(v)) {
+        sum += v;
+        ++cnt;
+      }
+    }
+    avg_bgr3[ch] = cnt ? sum / (double)cnt : 0.0;
+  }
+  return 0;
+}
+
+int derp_rephotograph(derp_ctx* c, int target, const uint16_t* const* colors, const float* const* disparities, int w,
+                      int h, float* out_bgra) {
+  if (!c || !colors || !disparities || !out_bgra || w <= 0 || h <= 0 || target < 0 || target >= c->S) {
+    return fail(c, "bad arguments");
+  }
+  if ((size_t)w * h > (1u << 24) || c->S > 256) {
+    return fail(c, "rephotography keys hold 24 bits of pixel index and 8 bits of camera index");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = (size_t)w * h;
+  DevBuf col, disp, key, out;
+  int rc = 0;
+  if (col.ensure((size_t)c->S * n * 6) || disp.ensure((size_t)c->S * n * 4) || key.ensure(n * 8) || out.ensure(n * 16)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    for (int s = 0; s < c->S && !rc; ++s) {
+      if (s == target) {
+        continue;
+      }
+      if (!colors[s] || !disparities[s]) {
+        rc = fail(c, "null colour / disparity for source %d", s);
+        break;
+      }
+      (void)hipMemcpy((char*)col.p + (size_t)s * n * 6, colors[s], n * 6, hipMemcpyHostToDevice);
+      (void)hipMemcpy((char*)disp.p + (size_t)s * n * 4, disparities[s], n * 4, hipMemcpyHostToDevice);
+    }
+    if (!rc) {
+      (void)hipMemsetAsync(key.p, 0xff, n * 8, c->stream);
+      hipLaunchKernelGGL(k_rephoto_splat, grid2d(w, h, c->S, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), target,
+                         disp.as<float>(), w, h, key.as<unsigned long long>());
+      hipLaunchKernelGGL(k_rephoto_resolve, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), target,
+                         col.as<uint16_t>(), key.as<unsigned long long>(), w, h, out.as<float4>());
+      if (hipStreamSynchronize(c->stream) != hipSuccess ||
+          hipMemcpy(out_bgra, out.p, n * 16, hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = fail(c, "HIP error in derp_rephotograph: %s", hipGetErrorString(hipGetLastError()));
+      }
+    }
+  }
+  for (DevBuf* b : {&col, &disp, &key, &out}) {
+    b->release();
+  }
+  return rc;
+}
+
 int derp_download_mismatch_mask(derp_ctx* c, int d, uint8_t* out) {
   TRY(need_current(c, false));
   if (d < 0 || d >= c->D || !out) {

@@ -1674,4 +1674,158 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
   out[idx] = weightedSumPix / sumWeight;
 }
 
+// ----------------------------------------------------------------------------------------
+// rephotography score — RephotographyUtil.h:38-116, ComputeRephotographyErrors.cpp:69-189.
+// Camera-space stand-in for the reference's OpenGL cubemaps: pass 1 z-buffers the
+// other cameras' points into the target image with a 64-bit atomicMin on (distance, camera, pixel),
+// pass 2 walks each covered target ray to that distance and fetches the winner's colour.
+// ----------------------------------------------------------------------------------------
+__global__ void k_rephoto_splat(const Cam* __restrict__ cams, int target, const float* __restrict__ disps, int W, int H,
+                                unsigned long long* __restrict__ key) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  const int j = blockIdx.z;
+  if (x >= W || y >= H || j == target) {
+    return;
+  }
+  const size_t n = (size_t)W * H, idx = (size_t)y * W + x;
+  const float d = disps[(size_t)j * n + idx];
+  if (!(d > 0) || isinf(d)) {
+    return;
+  }
+  const Cam& cj = cams[j];
+  const Cam& ct = cams[target];
+  const D3 dir = rig_direction(cj, (x + 0.5) / (double)W, (y + 0.5) / (double)H, cj.principal[0], cj.principal[1],
+                               cj.focal[0], cj.focal[1]);
+  const double depth = (double)(1.0f / d);
+  const D3 p = {cj.pos[0] + dir.x * depth, cj.pos[1] + dir.y * depth, cj.pos[2] + dir.z * depth};
+  D2 pn;
+  if (!sees(ct, p, ct.principal[0], ct.principal[1], ct.focal[0], ct.focal[1], 1.0, 1.0, pn)) {
+    return;
+  }
+  const double px = pn.x * (double)W, py = pn.y * (double)H;
+  const double dx = p.x - ct.pos[0], dy = p.y - ct.pos[1], dz = p.z - ct.pos[2];
+  const float dist = (float)sqrt(sum3(dx * dx, dy * dy, dz * dz));
+  const unsigned long long k =
+      ((unsigned long long)__float_as_uint(dist) << 32) | ((unsigned long long)j << 24) | (unsigned long long)idx;
+  const int x0 = (int)floor(px - 0.5), y0 = (int)floor(py - 0.5);
+  for (int yy = y0; yy <= y0 + 1; ++yy) {
+    for (int xx = x0; xx <= x0 + 1; ++xx) {
+      if (xx >= 0 && yy >= 0 && xx < W && yy < H) {
+        atomicMin(&key[(size_t)yy * W + xx], k);
+      }
+    }
+  }
+}
+
+// colours: S planes of interleaved BGR u16; out: BGRA float, alpha = covered
+__global__ void k_rephoto_resolve(const Cam* __restrict__ cams, int target, const uint16_t* __restrict__ colors,
+                                  const unsigned long long* __restrict__ key, int W, int H, float4* __restrict__ out) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const size_t n = (size_t)W * H, idx = (size_t)y * W + x;
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned long long k = key[idx];
+  if (k != ~0ull) {
+    const int j = (int)((k >> 24) & 0xff);
+    const float dist = __uint_as_float((unsigned)(k >> 32));
+    const Cam& ct = cams[target];
+    const Cam& cj = cams[j];
+    const D3 dir = rig_direction(ct, (x + 0.5) / (double)W, (y + 0.5) / (double)H, ct.principal[0], ct.principal[1],
+                                 ct.focal[0], ct.focal[1]);
+    const double depth = (double)dist;
+    const D3 p = {ct.pos[0] + dir.x * depth, ct.pos[1] + dir.y * depth, ct.pos[2] + dir.z * depth};
+    D2 pn;
+    if (sees(cj, p, cj.principal[0], cj.principal[1], cj.focal[0], cj.focal[1], 1.0, 1.0, pn)) {
+      // getPixelBilinear on Vec3w (CvUtil.h:78-120): clamp-to-edge taps, truncating u16 blend
+      const float sx = (float)(pn.x * (double)W), sy = (float)(pn.y * (double)H);
+      const float xf = roundf(sx), yf = roundf(sy);
+      const int xi = (int)xf, yi = (int)yf;
+      const float xw = sx - xf + 0.5f, yw = sy - yf + 0.5f;
+      const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
+      const int xa = min(max(xi - 1, 0), W - 1), xb = min(max(xi, 0), W - 1);
+      const int ya = min(max(yi - 1, 0), H - 1), yb = min(max(yi, 0), H - 1);
+      const uint16_t* c = colors + (size_t)j * n * 3;
+      const uint16_t* p00 = c + ((size_t)ya * W + xa) * 3;
+      const uint16_t* p01 = c + ((size_t)ya * W + xb) * 3;
+      const uint16_t* p10 = c + ((size_t)yb * W + xa) * 3;
+      const uint16_t* p11 = c + ((size_t)yb * W + xb) * 3;
+      const float s = 1.0f / 65535.0f;
+      o.x = bilerp_u16((float)p00[0], (float)p01[0], (float)p10[0], (float)p11[0], w00, w01, w10, w11) * s;
+      o.y = bilerp_u16((float)p00[1], (float)p01[1], (float)p10[1], (float)p11[1], w00, w01, w10, w11) * s;
+      o.z = bilerp_u16((float)p00[2], (float)p01[2], (float)p10[2], (float)p11[2], w00, w01, w10, w11) * s;
+      o.w = 1.0f;
+    }
+  }
+  out[idx] = o;
+}
+
+// rephoto_util::blur = cv::GaussianBlur(ksize 2r+1, sigma 1.5) on CV_32FC3, one separable pass:
+// k0 * x0 + k1 * (x-1 + x1) + ... in float, BORDER_REFLECT_101. `coef` = centre .. outermost tap.
+struct GaussCoef {
+  float k[16];
+};
+__device__ __forceinline__ int reflect101_dev(int p, int n) {
+  if (n == 1) {
+    return 0;
+  }
+  while (p < 0 || p >= n) {
+    p = p < 0 ? -p : 2 * (n - 1) - p;
+  }
+  return p;
+}
+__global__ void k_gauss_f32c3(const float* __restrict__ in, float* __restrict__ out, int W, int H, int radius,
+                              GaussCoef coef, int vertical) {
+  const int xc = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (xc >= W * 3 || y >= H) {
+    return;
+  }
+  const int x = xc / 3, c = xc - 3 * x;
+  float s = in[((size_t)y * W + x) * 3 + c] * coef.k[0];
+  for (int i = 1; i <= radius; ++i) {
+    float a, b;
+    if (vertical) {
+      a = in[((size_t)reflect101_dev(y - i, H) * W + x) * 3 + c];
+      b = in[((size_t)reflect101_dev(y + i, H) * W + x) * 3 + c];
+    } else {
+      a = in[((size_t)y * W + reflect101_dev(x - i, W)) * 3 + c];
+      b = in[((size_t)y * W + reflect101_dev(x + i, W)) * 3 + c];
+    }
+    s += (a + b) * coef.k[i];
+  }
+  out[((size_t)y * W + x) * 3 + c] = s;
+}
+
+// computeSSIM (RephotographyUtil.h:38-86), element-wise parts
+__global__ void k_ssim_moments(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ muX,
+                               const float* __restrict__ muY, float* __restrict__ a, float* __restrict__ b,
+                               float* __restrict__ c, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += step) {
+    const float dx = x[i] - muX[i], dy = y[i] - muY[i];
+    a[i] = dx * dx;
+    b[i] = dy * dy;
+    c[i] = dx * dy;
+  }
+}
+__global__ void k_ssim_score(const float* __restrict__ muX, const float* __restrict__ muY,
+                             const float* __restrict__ sig2X, const float* __restrict__ sig2Y,
+                             const float* __restrict__ sigXY, int useLuminance, int useContrast, int useStructure,
+                             float* __restrict__ out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  const float c1 = 0.0001f, c2 = 0.0009f, c3 = (float)((double)0.0009f / 2.0);
+  for (; i < n; i += step) {
+    const float mu2X = muX[i] * muX[i], mu2Y = muY[i] * muY[i], muXY = muX[i] * muY[i];
+    const float sigX = sqrtf(sig2X[i]), sigY = sqrtf(sig2Y[i]);
+    const float sxy = sigX * sigY;
+    const float luminance = useLuminance ? (2 * muXY + c1) * (1.0f / (mu2X + mu2Y + c1)) : 1.0f;
+    const float contrast = useContrast ? (2 * sxy + c2) * (1.0f / (sig2X[i] + sig2Y[i] + c2)) : 1.0f;
+    const float structure = useStructure ? (sigXY[i] + c3) * (1.0f / (sxy + c3)) : 1.0f;
+    out[i] = contrast * luminance * structure;
+  }
+}
+
 }  // namespace derp

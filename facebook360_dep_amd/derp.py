@@ -45,6 +45,7 @@ EXPORTS = [
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
     "derp_stage_ping_pong", "derp_stage_mismatches", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
+    "derp_ssim", "derp_average_score", "derp_rephotograph",
     "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
@@ -321,6 +322,27 @@ class Derp:
         self._ck(lib().derp_layer_disparities(self.h, _p(fg), _p(bg), C.c_size_t(fg.size), _p(out)))
         return out
 
+    # ---- rephotography score (RephotographyUtil.h, ComputeRephotographyErrors.cpp)
+    def ssim(self, x, y, blur_radius=1, alpha=1.0, beta=1.0, gamma=1.0):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        h, w = x.shape[:2]
+        out = np.zeros((h, w, 3), dtype=np.float32)
+        self._ck(lib().derp_ssim(self.h, _p(x), _p(y), w, h, blur_radius, C.c_float(alpha), C.c_float(beta),
+                                 C.c_float(gamma), _p(out)))
+        return out
+
+    def rephotograph(self, target, colors, disps):
+        """colors[s] u16 [h, w, 3], disps[s] f32 [h, w] for every source camera -> BGRA f32 [h, w, 4]."""
+        colors = [np.ascontiguousarray(c, dtype=np.uint16) for c in colors]
+        disps = [np.ascontiguousarray(d, dtype=np.float32) for d in disps]
+        h, w = disps[0].shape
+        cp = (C.c_void_p * len(colors))(*[c.ctypes.data for c in colors])
+        dp = (C.c_void_p * len(disps))(*[d.ctypes.data for d in disps])
+        out = np.zeros((h, w, 4), dtype=np.float32)
+        self._ck(lib().derp_rephotograph(self.h, target, cp, dp, w, h, _p(out)))
+        return out
+
     def fov_mask(self, d, w, h):
         out = np.zeros((h, w), dtype=np.uint8)
         self._ck(lib().derp_fov_mask(self.h, d, w, h, _p(out)))
@@ -447,3 +469,19 @@ def host_nth_element_pairs(pairs, nth):
 
 def host_minstd_uniform(seed, draw_index, a, b):
     return lib().derp_host_minstd_uniform(seed, draw_index, C.c_float(a), C.c_float(b))
+
+
+def average_score(score, mask):
+    """rephoto_util::averageScore -> [B, G, R] means over mask != 0 and not-NaN."""
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = mask.shape
+    out = (C.c_double * 3)()
+    if lib().derp_average_score(_p(score), _p(mask), w, h, out):
+        raise DerpError("derp_average_score: bad arguments")
+    return [out[0], out[1], out[2]]
+
+
+def format_results(avg):
+    """rephoto_util::formatResults (RephotographyUtil.h:110-116)."""
+    return "R %.2f%%, G %.2f%%, B %.2f%%" % (100 * avg[2], 100 * avg[1], 100 * avg[0])

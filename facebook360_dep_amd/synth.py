@@ -111,7 +111,18 @@ def pixel_rays(cam, w, h, device=None):
     ys = (torch.arange(h, dtype=torch.float64, device=dev) + 0.5 - py) / fy
     sy, sx = torch.meshgrid(ys, xs, indexing="ij")
     norm = torch.sqrt(sx * sx + sy * sy)
-    theta = _undistort(norm, cam.get("distortion", (0, 0, 0)))
+    r = _undistort(norm, cam.get("distortion", (0, 0, 0)))
+    kind = cam.get("type", "FTHETA")  # sensor radius -> angle from the axis (Camera.h:344-378)
+    if kind == "FTHETA":
+        theta = r
+    elif kind == "RECTILINEAR":
+        theta = torch.atan(r)
+    elif kind == "EQUISOLID":
+        theta = 2 * torch.asin((r / 2).clamp(max=1.0))
+    elif kind == "ORTHOGRAPHIC":
+        theta = torch.asin(r.clamp(max=1.0))
+    else:
+        raise ValueError("unknown camera type %r" % kind)
     s = torch.where(norm > 0, torch.sin(theta) / norm.clamp_min(1e-300), torch.zeros_like(norm))
     unit = torch.stack([s * sx, s * sy, -torch.cos(theta)], -1)
     R = torch.tensor([cam["right"], cam["up"], [-v for v in cam["forward"]]], dtype=torch.float64, device=dev)

@@ -156,6 +156,21 @@ int derp_download_mismatch_mask(derp_ctx* ctx, int dst, uint8_t* out);
 /* layerDisparities (LayerDisparities.cpp:45-55): fg over bg where fg > 0, x255, saturate to 8 bit */
 int derp_layer_disparities(derp_ctx* ctx, const float* foreground, const float* background, size_t n,
                            uint8_t* out);
+/* ---- rephotography score ---------------------------------------------------- */
+/* rephoto_util::computeSSIM (RephotographyUtil.h:38-86) on two interleaved BGR float images in
+ * [0, 1]; alpha / beta / gamma must each be 0 or 1 (computeScoreMap, :110-123: MSSIM = 1,1,1 and
+ * NCC = 0,0,1). score = [h][w][3] float. */
+int derp_ssim(derp_ctx* ctx, const float* x_bgr, const float* y_bgr, int w, int h, int blur_radius, float alpha,
+              float beta, float gamma, float* score_bgr);
+/* rephoto_util::averageScore (RephotographyUtil.h:88-108): per-channel mean of the score over
+ * mask != 0 and not-NaN pixels, accumulated in double (host side, row-major order). */
+int derp_average_score(const float* score_bgr, const uint8_t* mask, int w, int h, double* avg_bgr3);
+/* Camera-space stand-in for ComputeRephotographyErrors.cpp:69-189 `generateCubemaps(removeOne(i))`:
+ * what the other source cameras' colour + disparity say camera `target` sees (point z-buffer + one
+ * bilinear fetch; no OpenGL). colors[s] = BGR u16 [h][w][3], disparities[s] = f32 [h][w] for every
+ * source camera s (entry `target` is ignored). out = BGRA float [h][w][4], alpha = covered. */
+int derp_rephotograph(derp_ctx* ctx, int target, const uint16_t* const* colors, const float* const* disparities,
+                      int w, int h, float* out_bgra);
 /* generateFovMasks for one destination camera at an arbitrary size (DerpUtil.cpp:259-276) */
 int derp_fov_mask(derp_ctx* ctx, int dst, int w, int h, uint8_t* out);
 /* upsampleDisparities for one camera (UpsampleDisparityLib.cpp:98-182). fg_mask / fg_mask_up /

@@ -1161,6 +1161,198 @@ static Img<uint8_t> generateForegroundMask(
   return mask;
 }
 
+// ---- source/render/RephotographyUtil.h:38-116 + ComputeRephotographyErrors.cpp:69-189 ----
+// (the reference's quality gate for DerpCLI.) The score arithmetic (computeSSIM,
+// averageScore, formatResults) is restated operation for operation. OpenCV-defined steps:
+//  * cv::GaussianBlur(ksize 2r+1, sigma 1.5) on CV_32FC3: getGaussianKernel(n, sigma, CV_32F) of
+//    OpenCV 4 = t_i = exp(-0.125 / sigma^2 * (2i - n + 1)^2) summed from the outside in, doubled,
+//    plus the centre 1, kernel = t_i * (1 / sum) rounded to float; separable row then column pass
+//    in float, symmetric form k0 * x0 + k1 * (x-1 + x1) + ..., BORDER_REFLECT_101. Whether OpenCV's
+//    SIMD build contracts those into FMAs is build dependent: this restatement does not (parity
+//    unpinned, like every OpenCV call site — SURVEY §8c).
+//  * MatExpr arithmetic in float: (2 * A + c) rounds once; 1.0f / M is an IEEE division; cv::pow with
+//    exponent 1 copies and with exponent 0 yields 1; cv::sqrt is IEEE.
+static std::vector<float> gaussianKernel32f(int radius, double sigma) {
+  const int n = 2 * radius + 1;
+  std::vector<double> t(radius);
+  const double scale2X = -0.125 / (sigma * sigma);
+  double sum = 0;
+  for (int i = 0, x = 1 - n; i < radius; ++i, x += 2) {
+    t[i] = std::exp((double)(x * x) * scale2X);
+    sum += t[i];
+  }
+  sum *= 2;
+  sum += 1;
+  const double mul = 1.0 / sum;
+  std::vector<float> k(n);
+  for (int i = 0; i < radius; ++i) {
+    k[i] = k[n - 1 - i] = (float)(t[i] * mul);
+  }
+  k[radius] = (float)mul;
+  return k;
+}
+
+// 3-channel interleaved float image blur (rephoto_util::blur)
+static std::vector<float> gaussianBlur32f(const std::vector<float>& in, int w, int h, int radius) {
+  const std::vector<float> k = gaussianKernel32f(radius, 1.5f);
+  std::vector<float> tmp(in.size()), out(in.size());
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      for (int c = 0; c < 3; ++c) {
+        float s = in[((size_t)y * w + x) * 3 + c] * k[radius];
+        for (int i = 1; i <= radius; ++i) {
+          const float a = in[((size_t)y * w + reflect101(x - i, w)) * 3 + c];
+          const float b = in[((size_t)y * w + reflect101(x + i, w)) * 3 + c];
+          s += (a + b) * k[radius + i];
+        }
+        tmp[((size_t)y * w + x) * 3 + c] = s;
+      }
+    }
+  }
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      for (int c = 0; c < 3; ++c) {
+        float s = tmp[((size_t)y * w + x) * 3 + c] * k[radius];
+        for (int i = 1; i <= radius; ++i) {
+          const float a = tmp[((size_t)reflect101(y - i, h) * w + x) * 3 + c];
+          const float b = tmp[((size_t)reflect101(y + i, h) * w + x) * 3 + c];
+          s += (a + b) * k[radius + i];
+        }
+        out[((size_t)y * w + x) * 3 + c] = s;
+      }
+    }
+  }
+  return out;
+}
+
+// RephotographyUtil.h:38-86 (alpha, beta, gamma in {0, 1}: MSSIM = 1,1,1; NCC = 0,0,1)
+static std::vector<float> computeSSIM(
+    const std::vector<float>& x, const std::vector<float>& y, int w, int h, int blurRadius, float alpha, float beta,
+    float gamma) {
+  const size_t n = x.size();
+  const std::vector<float> muX = gaussianBlur32f(x, w, h, blurRadius), muY = gaussianBlur32f(y, w, h, blurRadius);
+  std::vector<float> a(n), b(n), c(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float dx = x[i] - muX[i], dy = y[i] - muY[i];
+    a[i] = dx * dx;
+    b[i] = dy * dy;
+    c[i] = dx * dy;
+  }
+  const std::vector<float> sig2X = gaussianBlur32f(a, w, h, blurRadius), sig2Y = gaussianBlur32f(b, w, h, blurRadius),
+                           sigXY = gaussianBlur32f(c, w, h, blurRadius);
+  const float c1 = 0.0001f, c2 = 0.0009f, c3 = (float)((double)0.0009f / 2.0);
+  auto ipow = [](float v, float e) { return e == 0.0f ? 1.0f : e == 1.0f ? v : std::pow(v, e); };
+  std::vector<float> out(n);
+  for (size_t i = 0; i < n; ++i) {
+    const float mu2X = muX[i] * muX[i], mu2Y = muY[i] * muY[i], muXY = muX[i] * muY[i];
+    const float sigX = std::sqrt(sig2X[i]), sigY = std::sqrt(sig2Y[i]);
+    const float sxy = sigX * sigY;
+    const float luminance = ipow((2 * muXY + c1) * (1.0f / (mu2X + mu2Y + c1)), alpha);
+    const float contrast = ipow((2 * sxy + c2) * (1.0f / (sig2X[i] + sig2Y[i] + c2)), beta);
+    const float structure = ipow((sigXY[i] + c3) * (1.0f / (sxy + c3)), gamma);
+    out[i] = contrast * luminance * structure;
+  }
+  return out;
+}
+
+// RephotographyUtil.h:88-108: per channel mean over mask != 0 and finite-or-inf (NaN excluded), in double
+static void averageScore(const std::vector<float>& score, const uint8_t* mask, size_t npx, double out[3]) {
+  for (int c = 0; c < 3; ++c) {
+    double sum = 0;
+    size_t cnt = 0;
+    for (size_t i = 0; i < npx; ++i) {
+      const float v = score[i * 3 + c];
+      if (mask[i] && !std::isnan(v)) {
+        sum += v;
+        ++cnt;
+      }
+    }
+    out[c] = cnt ? sum / (double)cnt : 0.0;
+  }
+}
+
+// Camera-space rephotography: what the other cameras' colour + disparity say camera `target` sees.
+// The reference renders both sides as OpenGL cubemaps of disparity meshes centred on the target
+// camera (CanopyScene; out of scope). Here, pass 1: every valid pixel of every other camera becomes a
+// point at 1/disparity along its ray (dstToWorldPoint), is projected with Camera::sees into the
+// target image and its distance to the target position (float) is written to the 2x2 pixels whose
+// centres surround it; the smallest (distance, camera, pixel) key wins. Pass 2: each covered target
+// pixel's own ray is walked to that distance, the point is projected into the winning camera and its
+// colour fetched with getPixelBilinear. Output BGRA float in [0, 1], alpha = covered.
+static void rephotograph(
+    const Rig& rig, int target, const uint16_t* const* colors, const float* const* disps, int w, int h, float* outBgra) {
+  const size_t n = (size_t)w * h;
+  std::vector<uint64_t> key(n, ~0ull);
+  const Camera& camT = rig[target];
+  for (int j = 0; j < (int)rig.size(); ++j) {
+    if (j == target) {
+      continue;
+    }
+    for (int y = 0; y < h; ++y) {
+      for (int x = 0; x < w; ++x) {
+        const float d = disps[j][(size_t)y * w + x];
+        if (!(d > 0) || std::isinf(d)) {
+          continue;
+        }
+        const V3 p = dstToWorldPoint(rig[j], x, y, d, w, h);
+        V2 pix;
+        if (!worldToSrcPoint(pix, p, camT, w, h)) {
+          continue;
+        }
+        const double dx = p.x - camT.position.x, dy = p.y - camT.position.y, dz = p.z - camT.position.z;
+        const float dist = (float)std::sqrt(dx * dx + (dy * dy + dz * dz));
+        uint32_t bits;
+        std::memcpy(&bits, &dist, 4);
+        const uint64_t k = ((uint64_t)bits << 32) | ((uint64_t)j << 24) | (uint64_t)((size_t)y * w + x);
+        const int x0 = (int)std::floor(pix.x - 0.5), y0 = (int)std::floor(pix.y - 0.5);
+        for (int yy = y0; yy <= y0 + 1; ++yy) {
+          for (int xx = x0; xx <= x0 + 1; ++xx) {
+            if (xx >= 0 && yy >= 0 && xx < w && yy < h) {
+              uint64_t& slot = key[(size_t)yy * w + xx];
+              slot = std::min(slot, k);
+            }
+          }
+        }
+      }
+    }
+  }
+  const float s = 1.0f / 65535.0f;
+  std::vector<Img<Px3w>> imgs;
+  for (int j = 0; j < (int)rig.size(); ++j) {
+    Img<Px3w> im(w, h);
+    std::memcpy((void*)im.d.data(), colors[j], n * 6);
+    imgs.push_back(std::move(im));
+  }
+  for (int y = 0; y < h; ++y) {
+    for (int x = 0; x < w; ++x) {
+      const size_t i = (size_t)y * w + x;
+      float* o = outBgra + i * 4;
+      o[0] = o[1] = o[2] = o[3] = 0.0f;
+      if (key[i] == ~0ull) {
+        continue;
+      }
+      const int j = (int)((key[i] >> 24) & 0xff);
+      const uint32_t bits = (uint32_t)(key[i] >> 32);
+      float dist;
+      std::memcpy(&dist, &bits, 4);
+      V2 p = {(x + 0.5) / w, (y + 0.5) / h};
+      if (!camT.isNormalized()) {
+        p = {p.x * camT.resolution.x, p.y * camT.resolution.y};
+      }
+      const V3 pWorld = camT.rig(p, (double)dist);
+      V2 ps;
+      if (!worldToSrcPoint(ps, pWorld, rig[j], w, h)) {
+        continue;
+      }
+      const Px3w c = getPixelBilinear(imgs[j], float(ps.x), float(ps.y));
+      for (int k = 0; k < 3; ++k) {
+        o[k] = c.c[k] * s;
+      }
+      o[3] = 1.0f;
+    }
+  }
+}
+
 } // namespace oracle
 
 // =====================================================================
@@ -1618,6 +1810,28 @@ void oracle_minstd_uniform(int seed, int n, float a, float b, float* out) {
 void oracle_nth_element_pairs(float* pairs, int n, int nth) {
   std::pair<float, float>* p = reinterpret_cast<std::pair<float, float>*>(pairs);
   std::nth_element(p, p + nth, p + n);
+}
+
+// ---- rephotography score (RephotographyUtil.h) ----
+void oracle_gaussian_blur_f32c3(const float* src, int w, int h, int radius, float* out) {
+  const std::vector<float> in(src, src + (size_t)w * h * 3);
+  const std::vector<float> r = gaussianBlur32f(in, w, h, radius);
+  std::memcpy(out, r.data(), r.size() * 4);
+}
+void oracle_compute_ssim(
+    const float* x, const float* y, int w, int h, int blurRadius, float alpha, float beta, float gamma, float* out) {
+  const size_t n = (size_t)w * h * 3;
+  const std::vector<float> r =
+      computeSSIM(std::vector<float>(x, x + n), std::vector<float>(y, y + n), w, h, blurRadius, alpha, beta, gamma);
+  std::memcpy(out, r.data(), n * 4);
+}
+void oracle_average_score(const float* score, const uint8_t* mask, int w, int h, double* out3) {
+  const size_t n = (size_t)w * h;
+  averageScore(std::vector<float>(score, score + n * 3), mask, n, out3);
+}
+void oracle_rephotograph(
+    const OracleRig* r, int target, const uint16_t* const* colors, const float* const* disps, int w, int h, float* outBgra) {
+  rephotograph(r->cams, target, colors, disps, w, h, outBgra);
 }
 
 } // extern "C"

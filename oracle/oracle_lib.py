@@ -387,6 +387,51 @@ def layer_disparities(fg, bg):
     return out
 
 
+# ---- rephotography score (RephotographyUtil.h:38-116, ComputeRephotographyErrors.cpp:69-189) ----
+def gaussian_blur_f32c3(img, radius):
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    h, w = img.shape[:2]
+    out = np.zeros_like(img)
+    lib().oracle_gaussian_blur_f32c3(_p(img), w, h, radius, _p(out))
+    return out
+
+
+def compute_ssim(x, y, blur_radius=1, alpha=1.0, beta=1.0, gamma=1.0):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    h, w = x.shape[:2]
+    out = np.zeros_like(x)
+    lib().oracle_compute_ssim(_p(x), _p(y), w, h, blur_radius, C.c_float(alpha), C.c_float(beta), C.c_float(gamma),
+                              _p(out))
+    return out
+
+
+def average_score(score, mask):
+    score = np.ascontiguousarray(score, dtype=np.float32)
+    mask = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, w = mask.shape
+    out = (C.c_double * 3)()
+    lib().oracle_average_score(_p(score), _p(mask), w, h, out)
+    return [out[0], out[1], out[2]]
+
+
+def format_results(avg):
+    """rephoto_util::formatResults (RephotographyUtil.h:110-116): channel order is B, G, R in `avg`."""
+    return "R %.2f%%, G %.2f%%, B %.2f%%" % (100 * avg[2], 100 * avg[1], 100 * avg[0])
+
+
+def rephotograph(rig, target, colors, disps):
+    """rig: normalised Rig; colors[j] u16 [h, w, 3]; disps[j] f32 [h, w] -> BGRA f32 [h, w, 4]."""
+    colors = [np.ascontiguousarray(c, dtype=np.uint16) for c in colors]
+    disps = [np.ascontiguousarray(d, dtype=np.float32) for d in disps]
+    h, w = disps[0].shape
+    cp = (C.c_void_p * len(colors))(*[c.ctypes.data for c in colors])
+    dp = (C.c_void_p * len(disps))(*[d.ctypes.data for d in disps])
+    out = np.zeros((h, w, 4), dtype=np.float32)
+    lib().oracle_rephotograph(rig.h, target, cp, dp, w, h, _p(out))
+    return out
+
+
 def temporal_space_radius(level):
     return lib().oracle_temporal_space_radius(level)
 

@@ -519,6 +519,112 @@ def test_reference_test_rig_non_square(built):
     g2.close()
 
 
+def test_rephotography_score(small, gpu):
+    """computeSSIM / averageScore (RephotographyUtil.h:38-108) bit-exact against the
+    oracle, MSSIM and NCC, radii 1..3; camera-space rephotography (z-buffer + bilinear fetch) bit-exact."""
+    from facebook360_dep_amd import derp
+    from oracle import oracle_lib as O
+
+    rig, frame = small["rig"], small["frame"]
+    rng = np.random.default_rng(11)
+    w, h = 93, 61
+    x = rng.random((h, w, 3), dtype=np.float32)
+    y = np.clip(x + 0.1 * rng.standard_normal(x.shape).astype(np.float32), 0, 1).astype(np.float32)
+    y[5:9, 7:30] = 0  # flat patches: sigma = 0 on one side
+    x[40:48, 50:70] = 0.5
+    mask = (rng.random((h, w)) > 0.2).astype(np.uint8)
+    for radius in (1, 2, 3):
+        for abg in ((1, 1, 1), (0, 0, 1)):
+            ref = O.compute_ssim(x, y, radius, *abg)
+            got = gpu.ssim(x, y, radius, *abg)
+            assert _float_equal(got, ref) == 0, (radius, abg)
+            a_ref, a_got = O.average_score(ref, mask), derp.average_score(got, mask)
+            assert a_ref == a_got
+            assert derp.format_results(a_got) == O.format_results(a_ref)
+    assert 0.5 < derp.average_score(gpu.ssim(x, y), mask)[1] < 1.0
+    with pytest.raises(derp.DerpError):
+        gpu.ssim(x, y, 1, 0.5, 1, 1)
+    # rephotography with the level-0 truth disparity and with a NaN / zero / inf riddled one
+    R = O.Rig(rig["cameras"]).normalize()
+    cols = frame["color"][0]
+    truth = [np.asarray(t, dtype=np.float32) for t in frame["truth"]]
+    broken = [t.copy() for t in truth]
+    broken[1][10:20, :] = np.nan
+    broken[2][:, 30:40] = 0
+    broken[3][50:60, 50:60] = np.inf
+    for disps in (truth, broken):
+        for target in (0, len(cols) - 1, 2):
+            ref = O.rephotograph(R, target, cols, disps)
+            got = gpu.rephotograph(target, cols, disps)
+            assert _float_equal(got, ref) == 0
+            assert 0.2 < (ref[..., 3] > 0).mean() <= 1.0
+
+
+def _mixed_type_rig(res):
+    """Six cameras on a 40-degree arc, two each RECTILINEAR / EQUISOLID / ORTHOGRAPHIC plus FTHETA
+    neighbours, some with and some without distortion and explicit fov (Camera.h:301-378)."""
+    import math
+
+    from facebook360_dep_amd import synth
+
+    base = synth.make_rig(6, res, layout="arc")["cameras"]
+    spec = [
+        ("RECTILINEAR", 0.50, 0.75, (-0.02, 0.001, 0.0)),
+        ("FTHETA", 0.36, math.pi / 2, synth.DISTORTION),
+        ("EQUISOLID", 0.36, 1.4, (0.0, 0.0, 0.0)),
+        ("ORTHOGRAPHIC", 0.52, 1.2, (0.01, 0.0, 0.0)),
+        ("RECTILINEAR", 0.55, None, (0.0, 0.0, 0.0)),
+        ("EQUISOLID", 0.40, None, (-0.01, 0.002, -0.0005)),
+    ]
+    cams = []
+    for i, (cam, (kind, f, fov, dist)) in enumerate(zip(base, spec)):
+        az = math.radians(-20.0 + 8.0 * i)
+        fwd = np.array([math.cos(az), math.sin(az), 0.05 * ((i % 2) * 2 - 1)])
+        fw, up, right = synth._frame(fwd)
+        cam = dict(cam, type=kind, focal=[f * res, -f * res], forward=fw.tolist(), up=up.tolist(),
+                   right=right.tolist(), origin=(0.25 * fw).tolist())
+        cam.pop("fov", None)
+        cam.pop("distortion", None)
+        if fov is not None:
+            cam["fov"] = fov
+        if any(dist):
+            cam["distortion"] = list(dist)
+        cams.append(cam)
+    return {"cameras": cams}
+
+
+def test_camera_types(built):
+    """RECTILINEAR, EQUISOLID and ORTHOGRAPHIC cameras (Camera.h:301-378) through the whole pyramid:
+    warp tables (unproject + project), FOV masks and the cost loop's fp64 `sees` for every type."""
+    from facebook360_dep_amd import derp, synth
+
+    rig = _mixed_type_rig(120)
+    sizes = [(120, 120), (80, 80), (50, 50)]
+    frame = synth.make_frame(rig, sizes)
+    cnt = {}
+    ref = common.oracle_pyramid(rig, sizes, frame, 120, 120, counters=cnt, partial_coverage=True)
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid(sizes, 120, 120)
+    g.upload_frame(frame)
+    g.process_pyramid()
+    g.synchronize()
+    nbad = npx = nvalid = 0
+    for level in ref:
+        for d in range(6):
+            got = g.download_disparity(level, d)
+            bad, rel = common.compare_disparity(got, ref[level][d], TOL)
+            nbad += bad
+            npx += got.size
+            nvalid += int(np.isfinite(got).sum())
+    print("mixed camera types: %d of %d pixels outside 1e-4 (%d finite)" % (nbad, npx, nvalid))
+    assert nbad == 0
+    assert nvalid > 0.3 * npx
+    c = g.counters()
+    assert c["n_cost"] == sum(v["n_cost"] for v in cnt.values())
+    assert c["n_pair"] == sum(v["n_pair"] for v in cnt.values())
+    g.close()
+
+
 @pytest.mark.parametrize("opts", [
     dict(ping_pong_iterations=2),
     dict(random_proposals=0),

@@ -180,3 +180,43 @@ def test_resize_area_paths_vs_exact_area_average():
     f = rng.random((240, 320)).astype(np.float32)
     for dw, dh in ((160, 120), (100, 76), (40, 30)):
         assert np.abs(O.cv_resize_area(f, dw, dh) - synth.resize_area(f, dw, dh)).max() < 1e-6
+
+
+
+def test_ssim_vs_float64():
+    """computeSSIM restatement (RephotographyUtil.h:38-86) against a float64 numpy evaluation of the
+    same formula; averageScore's NaN / mask exclusion; formatResults' R, G, B order."""
+    rng = np.random.default_rng(5)
+    x = rng.random((37, 52, 3), dtype=np.float32)
+    y = np.clip(x + 0.05 * rng.standard_normal(x.shape).astype(np.float32), 0, 1).astype(np.float32)
+
+    def blur(a, r):
+        k = np.exp(-np.arange(-r, r + 1, dtype=np.float64) ** 2 / (2 * 1.5 ** 2))
+        k /= k.sum()
+        p = np.pad(a, ((r, r), (r, r), (0, 0)), mode="reflect")
+        t = sum(k[i] * p[:, i:i + a.shape[1]] for i in range(2 * r + 1))
+        return sum(k[i] * t[i:i + a.shape[0]] for i in range(2 * r + 1))
+
+    for r in (1, 2, 4):
+        assert np.abs(O.gaussian_blur_f32c3(x, r) - blur(x.astype(np.float64), r)).max() < 1e-6
+        X, Y = x.astype(np.float64), y.astype(np.float64)
+        mx, my = blur(X, r), blur(Y, r)
+        s2x, s2y, sxy = blur((X - mx) ** 2, r), blur((Y - my) ** 2, r), blur((X - mx) * (Y - my), r)
+        sx, sy = np.sqrt(s2x), np.sqrt(s2y)
+        c1, c2 = 1e-4, 9e-4
+        lum = (2 * mx * my + c1) / (mx * mx + my * my + c1)
+        con = (2 * sx * sy + c2) / (s2x + s2y + c2)
+        st = (sxy + c2 / 2) / (sx * sy + c2 / 2)
+        assert np.abs(O.compute_ssim(x, y, r) - con * lum * st).max() < 5e-5
+        assert np.abs(O.compute_ssim(x, y, r, 0, 0, 1) - st).max() < 5e-5
+    s = O.compute_ssim(x, x, 1)
+    assert s.min() > 0.99999 and s.max() <= 1.0
+    score = O.compute_ssim(x, y, 1)
+    score[3, 4, 1] = np.nan
+    mask = np.ones(x.shape[:2], np.uint8)
+    mask[:10] = 0
+    avg = O.average_score(score, mask)
+    sel = score[10:].reshape(-1, 3).astype(np.float64)
+    assert abs(avg[0] - sel[:, 0].mean()) < 1e-12
+    assert abs(avg[1] - np.nanmean(sel[:, 1])) < 1e-12
+    assert O.format_results([0.5, 0.25, 0.125]) == "R 12.50%, G 25.00%, B 50.00%"
