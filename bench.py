@@ -287,7 +287,9 @@ def main():
         "device": g.device_name(),
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sample = {"cfg2": 256, "cfg4": 256, "cfg1": 256}.get(args.config, min(res, 128))
+        # bounded sample sized for roughly 10-30 s of oracle time on this host's cores
+        cores_here = os.cpu_count() or 1
+        sample = min(res, 512 if cores_here >= 128 else 256 if cores_here >= 32 else 128)
         if args.cpu_sample != "auto":
             sample = int(args.cpu_sample)
         mpix, cores, desc, _ = cpu_baseline(n_cams, widths, sample)

@@ -129,10 +129,34 @@ __device__ __forceinline__ float bilerp_u16(float p00, float p01, float p10, flo
   return __builtin_truncf(v);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float a) {
+  return (v2f){a, a};
+}
+__device__ __forceinline__ v2f trunc2(v2f v) {
+  return (v2f){__builtin_truncf(v.x), __builtin_truncf(v.y)};
+}
+// low / high ushort of a packed texel word as (B, G)
+__device__ __forceinline__ v2f bg_of(unsigned u) {
+  return (v2f){(float)(u & 0xffff), (float)(u >> 16)};
+}
+
 struct PixCtx {
   D3 rayO, rayD;        // dst ray (Camera::rig(pixel) of the dst pixel centre)
-  float patch[9][3];    // dst colour 3x3, index (dx+1)*3 + (dy+1) — computeSSD's loop order
-  float dstBias[3];
+  // dst colour 3x3, index (dx+1)*3 + (dy+1) — computeSSD's loop order — laid out for packed fp32:
+  // (B, G) of every offset as one register pair; R of the offsets dx = -1 / +1 paired per dy
+  v2f patchBG[9];
+  v2f patchR02[3];
+  float patchR1[3];
+  v2f dstBiasBG;
+  float dstBiasR;
+  __device__ __forceinline__ float patch(int o, int c) const {
+    const int ix = o / 3, iy = o - 3 * ix;
+    return c == 0 ? patchBG[o].x : c == 1 ? patchBG[o].y : ix == 1 ? patchR1[iy] : ix == 0 ? patchR02[iy].x : patchR02[iy].y;
+  }
+  __device__ __forceinline__ float dstBias(int c) const {
+    return c == 0 ? dstBiasBG.x : c == 1 ? dstBiasBG.y : dstBiasR;
+  }
   float confidence;     // max(variance, kMinVar)
 };
 
@@ -165,15 +189,14 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
     const ushort4* r0 = bia + (size_t)(yi - 1 + kPadC) * pitch + (xi - 1 + kPadC);
     const u4a8 a = *reinterpret_cast<const u4a8*>(r0);
     const u4a8 b = *reinterpret_cast<const u4a8*>(r0 + pitch);
-    const float p00[3] = {(float)(a.x & 0xffff), (float)(a.x >> 16), (float)(a.y & 0xffff)};
-    const float p01[3] = {(float)(a.z & 0xffff), (float)(a.z >> 16), (float)(a.w & 0xffff)};
-    const float p10[3] = {(float)(b.x & 0xffff), (float)(b.x >> 16), (float)(b.y & 0xffff)};
-    const float p11[3] = {(float)(b.z & 0xffff), (float)(b.z >> 16), (float)(b.w & 0xffff)};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const float sb = bilerp_u16(p00[c], p01[c], p10[c], p11[c], w00, w01, w10, w11);
-      bias[c] = px.dstBias[c] - sb;
-    }
+    // (B, G) as one packed pair, R alone — same per-lane operations as bilerp_u16
+    const v2f sbBG = trunc2(splat2(w00) * bg_of(a.x) + splat2(w01) * bg_of(a.z) + splat2(w10) * bg_of(b.x) +
+                            splat2(w11) * bg_of(b.z));
+    const v2f bBG = px.dstBiasBG - sbBG;
+    bias[0] = bBG.x;
+    bias[1] = bBG.y;
+    bias[2] = px.dstBiasR - bilerp_u16((float)(a.y & 0xffff), (float)(a.w & 0xffff), (float)(b.y & 0xffff),
+                                       (float)(b.w & 0xffff), w00, w01, w10, w11);
   }
   // --- per-offset tap positions and weights
   int xi[3], yi[3];
@@ -200,49 +223,75 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
       raw[row][0] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
       raw[row][1] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
     }
-    float d0s[3][3], d1s[3][3];  // [ix][iy]
-    float lo[4][3], hi[4][3];    // converted texel rows iy and iy + 1
-    auto unpack = [](const u4a8& a, const u4a8& b, float (&t)[4][3]) {
-      t[0][0] = (float)(a.x & 0xffff);
-      t[0][1] = (float)(a.x >> 16);
-      t[0][2] = (float)(a.y & 0xffff);
-      t[1][0] = (float)(a.z & 0xffff);
-      t[1][1] = (float)(a.z >> 16);
-      t[1][2] = (float)(a.w & 0xffff);
-      t[2][0] = (float)(b.x & 0xffff);
-      t[2][1] = (float)(b.x >> 16);
-      t[2][2] = (float)(b.y & 0xffff);
-      t[3][0] = (float)(b.z & 0xffff);
-      t[3][1] = (float)(b.z >> 16);
-      t[3][2] = (float)(b.w & 0xffff);
+    // Packed fp32 (v_pk_mul_f32 / v_pk_add_f32 work on register pairs): channels B and G of one offset
+    // share every instruction, and so do the R channels of the offsets dx = -1 and dx = +1 (texel
+    // columns 0 / 2 and 1 / 3 are converted straight into such pairs). Each lane of a packed operation
+    // is the same IEEE operation as before, in the same order.
+    struct RowF {
+      v2f bg[4];   // (B, G) of texel columns 0..3
+      v2f rA, rB;  // R of columns (0, 2) and (1, 3)
     };
+    auto unpack = [](const u4a8& a, const u4a8& b, RowF& t) {
+      t.bg[0] = bg_of(a.x);
+      t.bg[1] = bg_of(a.z);
+      t.bg[2] = bg_of(b.x);
+      t.bg[3] = bg_of(b.z);
+      t.rA = (v2f){(float)(a.y & 0xffff), (float)(b.y & 0xffff)};
+      t.rB = (v2f){(float)(a.w & 0xffff), (float)(b.w & 0xffff)};
+    };
+    const v2f biasBG = (v2f){bias[0], bias[1]};
+    const v2f xw02 = (v2f){xw[0], xw[2]};
+    const v2f omx02 = splat2(1.0f) - xw02;
+    const float omx1 = 1 - xw[1];
+    float d0s[3][3], d1s[3][3];  // [ix][iy]
+    RowF lo, hi;
     unpack(raw[0][0], raw[0][1], lo);
 #pragma unroll
     for (int iy = 0; iy < 3; ++iy) {
       unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+      const float omy = 1 - yw[iy];
+      // weights of the offsets dx = -1 / +1 as pairs, of dx = 0 as scalars
+      const v2f w00p = omx02 * splat2(omy), w01p = xw02 * splat2(omy), w10p = omx02 * splat2(yw[iy]),
+                w11p = xw02 * splat2(yw[iy]);
+      const float w00m = omx1 * omy, w01m = xw[1] * omy, w10m = omx1 * yw[iy], w11m = xw[1] * yw[iy];
+      float bgd0[3], bgd1[3];
 #pragma unroll
       for (int ix = 0; ix < 3; ++ix) {
-        const float w00 = (1 - xw[ix]) * (1 - yw[iy]), w01 = xw[ix] * (1 - yw[iy]);
-        const float w10 = (1 - xw[ix]) * yw[iy], w11 = xw[ix] * yw[iy];
-        float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const float cs = bilerp_u16(lo[ix][c], lo[ix + 1][c], hi[ix][c], hi[ix + 1][c], w00, w01, w10, w11);
-          const float db = px.patch[ix * 3 + iy][c] - cs;
-          const float dn = db - bias[c];
-          d0 += db * db;
-          d1 += dn * dn;
-        }
-        d0s[ix][iy] = d0;
-        d1s[ix][iy] = d1;
+        const float w00 = ix == 1 ? w00m : ix == 0 ? w00p.x : w00p.y;
+        const float w01 = ix == 1 ? w01m : ix == 0 ? w01p.x : w01p.y;
+        const float w10 = ix == 1 ? w10m : ix == 0 ? w10p.x : w10p.y;
+        const float w11 = ix == 1 ? w11m : ix == 0 ? w11p.x : w11p.y;
+        const v2f v = splat2(w00) * lo.bg[ix] + splat2(w01) * lo.bg[ix + 1] + splat2(w10) * hi.bg[ix] +
+                      splat2(w11) * hi.bg[ix + 1];
+        const v2f db = px.patchBG[ix * 3 + iy] - trunc2(v);
+        const v2f dn = db - biasBG;
+        const v2f s0 = db * db, s1 = dn * dn;
+        // (0 + B) + G as two plain adds over the halves of the pairs; the empty asm keeps the SLP
+        // vectoriser from re-pairing them across offsets, which costs three v_mov per v_pk_add
+        float t0 = s0.x + s0.y, t1 = s1.x + s1.y;
+        asm("" : "+v"(t0), "+v"(t1));
+        bgd0[ix] = t0;
+        bgd1[ix] = t1;
       }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          lo[k][c] = hi[k][c];
-        }
+      {  // R of dx = -1 / +1
+        const v2f v = w00p * lo.rA + w01p * lo.rB + w10p * hi.rA + w11p * hi.rB;
+        const v2f db = px.patchR02[iy] - trunc2(v);
+        const v2f dn = db - splat2(bias[2]);
+        const v2f t0 = (v2f){bgd0[0], bgd0[2]} + db * db;
+        const v2f t1 = (v2f){bgd1[0], bgd1[2]} + dn * dn;
+        d0s[0][iy] = t0.x;
+        d0s[2][iy] = t0.y;
+        d1s[0][iy] = t1.x;
+        d1s[2][iy] = t1.y;
       }
+      {  // R of dx = 0: texel columns 1 and 2
+        const float v = w00m * lo.rB.x + w01m * lo.rA.y + w10m * hi.rB.x + w11m * hi.rA.y;
+        const float db = px.patchR1[iy] - __builtin_truncf(v);
+        const float dn = db - bias[2];
+        d0s[1][iy] = bgd0[1] + db * db;
+        d1s[1][iy] = bgd1[1] + dn * dn;
+      }
+      lo = hi;
     }
 #pragma unroll
     for (int ix = 0; ix < 3; ++ix) {
@@ -271,7 +320,7 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
         float d0 = 0.f, d1 = 0.f;
         for (int c = 0; c < 3; ++c) {
           const float cs = bilerp_u16(p00[c], p01[c], p10[c], p11[c], w00, w01, w10, w11);
-          const float db = px.patch[ix * 3 + iy][c] - cs;
+          const float db = px.patch(ix * 3 + iy, c) - cs;
           const float dn = db - bias[c];
           d0 += db * db;
           d1 += dn * dn;
@@ -375,15 +424,19 @@ __device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, 
 #pragma unroll
     for (int iy = 0; iy < 3; ++iy) {
       const ushort4 q = col[(size_t)(y + iy - 1) * V.W + (x + ix - 1)];
-      px.patch[ix * 3 + iy][0] = (float)q.x;
-      px.patch[ix * 3 + iy][1] = (float)q.y;
-      px.patch[ix * 3 + iy][2] = (float)q.z;
+      px.patchBG[ix * 3 + iy] = (v2f){(float)q.x, (float)q.y};
+      if (ix == 1) {
+        px.patchR1[iy] = (float)q.z;
+      } else if (ix == 0) {
+        px.patchR02[iy].x = (float)q.z;
+      } else {
+        px.patchR02[iy].y = (float)q.z;
+      }
     }
   }
   const ushort4 b = V.ownBias[(size_t)own * n + (size_t)y * V.W + x];
-  px.dstBias[0] = (float)b.x;
-  px.dstBias[1] = (float)b.y;
-  px.dstBias[2] = (float)b.z;
+  px.dstBiasBG = (v2f){(float)b.x, (float)b.y};
+  px.dstBiasR = (float)b.z;
   const float var = V.srcVar[(size_t)own * n + (size_t)y * V.W + x];
   px.confidence = fmaxf(var, kMinVar);
 }
