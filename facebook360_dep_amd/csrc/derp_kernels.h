@@ -198,35 +198,23 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
     bias[2] = px.dstBiasR - bilerp_u16((float)(a.y & 0xffff), (float)(a.w & 0xffff), (float)(b.y & 0xffff),
                                        (float)(b.w & 0xffff), w00, w01, w10, w11);
   }
-  // --- per-offset tap positions and weights
-  int xi[3], yi[3];
-  float xw[3], yw[3];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float xs = xDstSrc + (float)(k - 1), ys = yDstSrc + (float)(k - 1);
-    const float xf = roundf(xs), yf = roundf(ys);
-    xi[k] = (int)xf;
-    yi[k] = (int)yf;
-    xw[k] = xs - xf + 0.5f;
-    yw[k] = ys - yf + 0.5f;
-  }
+  // --- the 4x4 texel block arithmetic shared by the two block-shaped paths below. Packed fp32
+  // (v_pk_mul_f32 / v_pk_add_f32 work on register pairs): channels B and G of one offset share every
+  // instruction, and so do the R channels of the offsets dx = -1 and dx = +1 (texel columns 0 / 2 and
+  // 1 / 3 are converted straight into such pairs). Each lane of a packed operation is the same IEEE
+  // operation, in the same order, as the scalar expression it replaces. Rows are streamed two at a
+  // time: offset row iy needs texel rows iy and iy+1 only; the per-offset sums are parked and added
+  // in the reference's dx-outer / dy-inner order afterwards.
+  // xwp = (xw[0], xw[2]), xwm = xw[1]; yw[iy] per offset row.
   float first = 0.f, second = 0.f;
-  const bool regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
-  if (regular) {
-    // 4x4 texel block rows yi[1]-2 .. yi[1]+1, cols xi[1]-2 .. xi[1]+1, streamed two rows at a time:
-    // offset row iy needs texel rows iy and iy+1 only, so at most two converted rows are live (the
-    // per-offset sums are parked and added in the reference's dx-outer / dy-inner order afterwards).
-    const ushort4* r = col + (size_t)(yi[1] - 2 + kPadC) * pitch + (xi[1] - 2 + kPadC);
+  auto block = [&](int xi1, int yi1, v2f xwp, float xwm, const float (&yw)[3]) {
+    const ushort4* r = col + (size_t)(yi1 - 2 + kPadC) * pitch + (xi1 - 2 + kPadC);
     u4a8 raw[4][2];
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
       raw[row][0] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
       raw[row][1] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
     }
-    // Packed fp32 (v_pk_mul_f32 / v_pk_add_f32 work on register pairs): channels B and G of one offset
-    // share every instruction, and so do the R channels of the offsets dx = -1 and dx = +1 (texel
-    // columns 0 / 2 and 1 / 3 are converted straight into such pairs). Each lane of a packed operation
-    // is the same IEEE operation as before, in the same order.
     struct RowF {
       v2f bg[4];   // (B, G) of texel columns 0..3
       v2f rA, rB;  // R of columns (0, 2) and (1, 3)
@@ -240,9 +228,8 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
       t.rB = (v2f){(float)(a.w & 0xffff), (float)(b.w & 0xffff)};
     };
     const v2f biasBG = (v2f){bias[0], bias[1]};
-    const v2f xw02 = (v2f){xw[0], xw[2]};
-    const v2f omx02 = splat2(1.0f) - xw02;
-    const float omx1 = 1 - xw[1];
+    const v2f omxp = splat2(1.0f) - xwp;
+    const float omxm = 1 - xwm;
     float d0s[3][3], d1s[3][3];  // [ix][iy]
     RowF lo, hi;
     unpack(raw[0][0], raw[0][1], lo);
@@ -251,9 +238,9 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
       unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
       const float omy = 1 - yw[iy];
       // weights of the offsets dx = -1 / +1 as pairs, of dx = 0 as scalars
-      const v2f w00p = omx02 * splat2(omy), w01p = xw02 * splat2(omy), w10p = omx02 * splat2(yw[iy]),
-                w11p = xw02 * splat2(yw[iy]);
-      const float w00m = omx1 * omy, w01m = xw[1] * omy, w10m = omx1 * yw[iy], w11m = xw[1] * yw[iy];
+      const v2f w00p = omxp * splat2(omy), w01p = xwp * splat2(omy), w10p = omxp * splat2(yw[iy]),
+                w11p = xwp * splat2(yw[iy]);
+      const float w00m = omxm * omy, w01m = xwm * omy, w10m = omxm * yw[iy], w11m = xwm * yw[iy];
       float bgd0[3], bgd1[3];
 #pragma unroll
       for (int ix = 0; ix < 3; ++ix) {
@@ -301,6 +288,37 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
         second += d1s[ix][iy];
       }
     }
+  };
+  // --- per-offset tap positions and weights. The reference evaluates round(x + dx) and the weight
+  // x + dx - round(x + dx) + 0.5 for each dx in {-1, 0, 1}. When x >= 1 and fl(x + 1) is exact (checked
+  // by subtracting the 1 again) all of x - 1, x, x + 1 are exact, so round(x + dx) = round(x) + dx and
+  // the three weights are the same float (x + dx - round(x + dx) is exact by Sterbenz's lemma and equal
+  // to x - round(x)): one rounding and one weight serve the three offsets. That holds except on the
+  // first texel column / row and where x + 1 crosses into a binade that drops x's last bit.
+  const float xfc = roundf(xDstSrc), yfc = roundf(yDstSrc);
+  const bool exact = (xDstSrc >= 1.0f) && (yDstSrc >= 1.0f) && ((xDstSrc + 1.0f) - 1.0f == xDstSrc) &&
+                     ((yDstSrc + 1.0f) - 1.0f == yDstSrc);
+  int xi[3], yi[3];
+  float xw[3], yw[3];
+  bool regular = true;
+  xi[1] = (int)xfc;
+  yi[1] = (int)yfc;
+  xw[0] = xw[1] = xw[2] = xDstSrc - xfc + 0.5f;
+  yw[0] = yw[1] = yw[2] = yDstSrc - yfc + 0.5f;
+  if (!exact) {
+#pragma unroll
+    for (int k = 0; k < 3; k += 2) {
+      const float xs = xDstSrc + (float)(k - 1), ys = yDstSrc + (float)(k - 1);
+      const float xf = roundf(xs), yf = roundf(ys);
+      xi[k] = (int)xf;
+      yi[k] = (int)yf;
+      xw[k] = xs - xf + 0.5f;
+      yw[k] = ys - yf + 0.5f;
+    }
+    regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
+  }
+  if (regular) {
+    block(xi[1], yi[1], (v2f){xw[0], xw[2]}, xw[1], yw);
   } else {
     // float rounding of x + dx crossed a .5 boundary: taps no longer form a 4x4 block
     for (int ix = 0; ix < 3; ++ix) {
