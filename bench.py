@@ -273,6 +273,11 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "traffic_GBps": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic and kernel_ms > 0 else None),
+            "note": ("achieved / frac price the ALGORITHMIC bytes of SURVEY 8(d) (64 B per cost call + 272 B per "
+                     "(call, source) pair as the reference issues them); neighbouring pixels share texels, so "
+                     "L1/L2 serve most of them and frac can pass 1.0 — traffic is what crossed HBM "
+                     "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)"),
             "kernel_ms": round(kernel_ms, 3),
             "algorithmic_bytes_per_launch": alg_bytes,
             "n_cost_per_launch": pp["n_cost"] / launches,

@@ -16,8 +16,8 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 src, dst = "gpurun_out", "profiles"
 rows = list(csv.reader(open(os.path.join(src, tag + "_kernel_stats_full.csv"))))
 hdr, body = rows[0], rows[1:]
-keep = [r for r in body if r[0].startswith("derp::")]
-other = [r for r in body if not r[0].startswith("derp::")]
+keep = [r for r in body if "derp::" in r[0]]  # templates print as "void derp::k<...>(...)"
+other = [r for r in body if "derp::" not in r[0]]
 with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(hdr)
@@ -28,7 +28,7 @@ with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     d = json.load(open(os.path.join(src, "%s_pmc_%s.json" % (tag, c))))
-    d = {k: v for k, v in d.items() if k.startswith("derp::")}
+    d = {k: v for k, v in d.items() if "derp::" in k}
     json.dump(d, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, c)), "w"), indent=1, sort_keys=True)
     pm[c] = d
 for f in ("_bench.json", "_bench_under_rocprof.json"):
