@@ -220,6 +220,39 @@ def test_temporal_filter(small, gpu):
         assert bad == 0, (off, cnt, bad, rel)
 
 
+def test_config3_temporal_filter_full_size_properties(built):
+    """BASELINE config 3's filter stage at 2048^2 (one camera, 5 frames of the moving scene) through
+    properties of temporalJointBilateralFilter (TemporalBilateralFilter.h:126-172): the weights depend
+    on the colour guides only, so scaling every disparity by 2 scales the result by exactly 2; identical
+    frames give back the input (to rounding); pixels outside the mask pass through untouched; the
+    window clamped at the start of the sequence (populateMinMaxFrame) is a different, valid filter."""
+    from facebook360_dep_amd import derp, synth
+
+    res = 2048
+    rig = synth.make_rig(16, res)
+    cam = rig["cameras"][3]
+    frames = [synth.render_camera(cam, res, res, frame=f, device="cuda") for f in range(5)]
+    guides = [f[0] for f in frames]
+    disps = [np.asarray(f[1], dtype=np.float32) for f in frames]
+    rng = np.random.default_rng(3)
+    masks = [(rng.random((res, res)) > 0.02).astype(np.uint8) for _ in range(5)]
+    g = derp.Derp(rig["cameras"])
+    args = (0.01, 1, 0.5, 1.0, 0.5)  # sigma, space radius, weights (b, g, b) — TemporalBilateralFilter.cpp:55,165-178
+    out = g.temporal_filter(guides, disps, masks, 2, *args)
+    assert np.isfinite(out[masks[2] == 1]).all()
+    assert np.array_equal(out[masks[2] == 0], disps[2][masks[2] == 0])
+    lo, hi = np.minimum.reduce(disps), np.maximum.reduce(disps)
+    m = masks[2] == 1
+    assert (out[m] >= lo[m] * (1 - 1e-5)).all() and (out[m] <= hi[m] * (1 + 1e-5)).all()  # a convex combination
+    out2 = g.temporal_filter(guides, [2.0 * d for d in disps], masks, 2, *args)
+    assert np.array_equal(out2, 2.0 * out)
+    same = g.temporal_filter([guides[2]] * 5, [disps[2]] * 5, [masks[2]] * 5, 2, *args)
+    assert np.abs(same[m] - disps[2][m]).max() <= 4e-6 * disps[2][m].max()
+    head = g.temporal_filter(guides[:3], disps[:3], masks[:3], 0, *args)  # frame 0 of the sequence: window [0, 2]
+    assert np.isfinite(head[masks[0] == 1]).all() and not np.array_equal(head, out)
+    g.close()
+
+
 def _run_pyramid(small, **opts):
     from facebook360_dep_amd import derp
 
