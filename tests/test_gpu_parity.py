@@ -314,6 +314,40 @@ def test_destination_subset(small):
     g.close()
 
 
+def test_destination_batching(small, monkeypatch):
+    """Config 4's memory path: when the projection tables of all destinations do not fit the table
+    budget, destinations are processed in batches (DERP_TABLE_BUDGET_GB caps the budget; 7 MB here
+    leaves room for two of the six). Results and counters must not depend on the batch size."""
+    from facebook360_dep_amd import derp
+
+    def run():
+        g = derp.Derp(small["rig"]["cameras"], partial_coverage=1)
+        g.set_pyramid(small["sizes"], small["res"], small["res"])
+        g.upload_frame({"color": small["frame"]["color"]})
+        g.process_pyramid()
+        g.synchronize()
+        out = [[g.download_disparity(level, d) for d in range(small["n"])] for level in range(len(small["sizes"]))]
+        c = g.counters()
+        g.close()
+        return out, c
+
+    whole, c_whole = run()
+    for budget in ("0.007", "0.004"):
+        monkeypatch.setenv("DERP_TABLE_BUDGET_GB", budget)
+        batched, c_batched = run()
+        assert c_batched == c_whole
+        for a, b in zip(whole, batched):
+            for x, y in zip(a, b):
+                assert _float_equal(x, y) == 0
+    monkeypatch.setenv("DERP_TABLE_BUDGET_GB", "0.0001")
+    g = derp.Derp(small["rig"]["cameras"], partial_coverage=1)
+    g.set_pyramid(small["sizes"], small["res"], small["res"])
+    g.upload_frame({"color": small["frame"]["color"]})
+    with pytest.raises(derp.DerpError, match="table budget"):
+        g.process_pyramid()
+    g.close()
+
+
 def test_sixteen_camera_rig_full_pyramid(built):
     """BASELINE config 2's camera count (16 on a Fibonacci sphere, up to 15 sources per cost, which
     exercises every branch of the nth_element restatement) at a size the oracle finishes in seconds."""
