@@ -20,7 +20,7 @@
 
 namespace derp {
 
-struct SsdPair {
+struct alignas(8) SsdPair {  // 8-byte aligned: one ds_read_b64 / ds_write_b64 per LDS slot access
   float first, second;
 };
 
