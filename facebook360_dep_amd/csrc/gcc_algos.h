@@ -54,37 +54,42 @@ struct GccSelect {
 
   // __move_median_to_first(result, a, b, c)
   DERP_HD void move_median_to_first(int result, int ia, int ib, int ic) {
-    if (lt(ia, ib)) {
-      if (lt(ib, ic)) {
-        swap(result, ib);
-      } else if (lt(ia, ic)) {
-        swap(result, ic);
-      } else {
-        swap(result, ia);
-      }
-    } else if (lt(ia, ic)) {
-      swap(result, ia);
-    } else if (lt(ib, ic)) {
-      swap(result, ic);
+    // three reads, then the same decision tree on register values
+    const SsdPair pa = a.get(ia), pb = a.get(ib), pc = a.get(ic);
+    const unsigned long long ka = pair_key(pa), kb = pair_key(pb), kc = pair_key(pc);
+    int m;
+    if (ka < kb) {
+      m = (kb < kc) ? ib : (ka < kc) ? ic : ia;
     } else {
-      swap(result, ib);
+      m = (ka < kc) ? ia : (kb < kc) ? ic : ib;
     }
+    const SsdPair pm = (m == ia) ? pa : (m == ib) ? pb : pc;
+    const SsdPair pr = a.get(result);
+    a.set(result, pm);
+    a.set(m, pr);
   }
 
   // __unguarded_partition(first, last, pivot)
   DERP_HD int unguarded_partition(int first, int last, int pivot) {
+    // the pivot sits below `first` and is never swapped here: read its key once
+    const unsigned long long kp = pair_key(a.get(pivot));
     for (;;) {
-      while (lt(first, pivot)) {
+      SsdPair pf = a.get(first);
+      while (pair_key(pf) < kp) {
         ++first;
+        pf = a.get(first);
       }
       --last;
-      while (lt(pivot, last)) {
+      SsdPair pl = a.get(last);
+      while (kp < pair_key(pl)) {
         --last;
+        pl = a.get(last);
       }
       if (!(first < last)) {
         return first;
       }
-      swap(first, last);
+      a.set(first, pl);  // iter_swap(first, last) with both values already in registers
+      a.set(last, pf);
       ++first;
     }
   }
@@ -201,7 +206,36 @@ struct GccSelect {
         last = cut;
       }
     }
-    insertion_sort(first, last);
+    insertion_sort3(first, last);
+  }
+
+  // __insertion_sort over the at most three elements introselect leaves: elements move on strict
+  // "less" only, i.e. the result is the stable order of the keys — computed on register copies
+  DERP_HD void insertion_sort3(int first, int last) {
+    const int cnt = last - first;
+    if (cnt < 2) {
+      return;
+    }
+    SsdPair p0 = a.get(first), p1 = a.get(first + 1);
+    if (pair_key(p1) < pair_key(p0)) {
+      const SsdPair t = p0;
+      p0 = p1;
+      p1 = t;
+    }
+    if (cnt == 3) {
+      const SsdPair p2 = a.get(first + 2);
+      const unsigned long long k2 = pair_key(p2);
+      if (k2 < pair_key(p0)) {
+        a.set(first + 2, p1);
+        p1 = p0;
+        p0 = p2;
+      } else if (k2 < pair_key(p1)) {
+        a.set(first + 2, p1);
+        p1 = p2;
+      }
+    }
+    a.set(first, p0);
+    a.set(first + 1, p1);
   }
 };
 
