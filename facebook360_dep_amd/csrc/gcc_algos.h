@@ -53,7 +53,8 @@ struct GccSelect {
   }
 
   // __move_median_to_first(result, a, b, c)
-  DERP_HD void move_median_to_first(int result, int ia, int ib, int ic) {
+  // returns the key of the element it moved to `result`
+  DERP_HD unsigned long long move_median_to_first(int result, int ia, int ib, int ic) {
     // three reads, then the same decision tree on register values
     const SsdPair pa = a.get(ia), pb = a.get(ib), pc = a.get(ic);
     const unsigned long long ka = pair_key(pa), kb = pair_key(pb), kc = pair_key(pc);
@@ -67,12 +68,12 @@ struct GccSelect {
     const SsdPair pr = a.get(result);
     a.set(result, pm);
     a.set(m, pr);
+    return pair_key(pm);
   }
 
   // __unguarded_partition(first, last, pivot)
-  DERP_HD int unguarded_partition(int first, int last, int pivot) {
-    // the pivot sits below `first` and is never swapped here: read its key once
-    const unsigned long long kp = pair_key(a.get(pivot));
+  // `kp` = key of the pivot, which sits below `first` and is never swapped here
+  DERP_HD int unguarded_partition(int first, int last, unsigned long long kp) {
     for (;;) {
       SsdPair pf = a.get(first);
       while (pair_key(pf) < kp) {
@@ -96,8 +97,8 @@ struct GccSelect {
 
   DERP_HD int unguarded_partition_pivot(int first, int last) {
     const int mid = first + (last - first) / 2;
-    move_median_to_first(first, first + 1, mid, last - 1);
-    return unguarded_partition(first + 1, last, first);
+    const unsigned long long kp = move_median_to_first(first, first + 1, mid, last - 1);
+    return unguarded_partition(first + 1, last, kp);
   }
 
   // __insertion_sort(first, last)
@@ -187,11 +188,7 @@ struct GccSelect {
     if (first == last || nth == last) {
       return;
     }
-    int depth_limit = 0;  // std::__lg(n) * 2
-    for (int t = n; t > 1; t >>= 1) {
-      ++depth_limit;
-    }
-    depth_limit *= 2;
+    int depth_limit = 2 * (31 - __builtin_clz((unsigned)n));  // std::__lg(n) * 2
     while (last - first > 3) {
       if (depth_limit == 0) {
         heap_select(first, nth + 1, last);
