@@ -179,6 +179,19 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
   return {xDstSrc * 1e-3f, yDstSrc * 1e-3f};
 #endif
   const int pitch = V.W + 2 * kPadC;
+  // The 4x4 texel block around round(x, y) (rows yi-2..yi+1, cols xi-2..xi+1) is requested here, together
+  // with the bias taps, so that one wait covers both; it lies inside the padded table for every x, y
+  // the tables can produce, and only the rare path at the bottom (taps not block shaped) ignores it.
+  u4a8 raw[4][2];
+  {
+    const int xi = (int)roundf(xDstSrc), yi = (int)roundf(yDstSrc);
+    const ushort4* r = col + (size_t)(yi - 2 + kPadC) * pitch + (xi - 2 + kPadC);
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      raw[row][0] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
+      raw[row][1] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
+    }
+  }
   // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
   float bias[3];
   {
@@ -207,14 +220,7 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
   // in the reference's dx-outer / dy-inner order afterwards.
   // xwp = (xw[0], xw[2]), xwm = xw[1]; yw[iy] per offset row.
   float first = 0.f, second = 0.f;
-  auto block = [&](int xi1, int yi1, v2f xwp, float xwm, const float (&yw)[3]) {
-    const ushort4* r = col + (size_t)(yi1 - 2 + kPadC) * pitch + (xi1 - 2 + kPadC);
-    u4a8 raw[4][2];
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-      raw[row][0] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
-      raw[row][1] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
-    }
+  auto block = [&](v2f xwp, float xwm, const float (&yw)[3]) {
     struct RowF {
       v2f bg[4];   // (B, G) of texel columns 0..3
       v2f rA, rB;  // R of columns (0, 2) and (1, 3)
@@ -318,7 +324,7 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
     regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
   }
   if (regular) {
-    block(xi[1], yi[1], (v2f){xw[0], xw[2]}, xw[1], yw);
+    block((v2f){xw[0], xw[2]}, xw[1], yw);
   } else {
     // float rounding of x + dx crossed a .5 boundary: taps no longer form a 4x4 block
     for (int ix = 0; ix < 3; ++ix) {
