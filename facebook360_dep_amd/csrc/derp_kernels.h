@@ -185,11 +185,14 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
   u4a8 raw[4][2];
   {
     const int xi = (int)roundf(xDstSrc), yi = (int)roundf(yDstSrc);
-    const ushort4* r = col + (size_t)(yi - 2 + kPadC) * pitch + (xi - 2 + kPadC);
+    // one table plane is far below 4 GB: 32-bit byte offsets from the (wave-uniform) plane base let the
+    // loads use the scalar-base + 32-bit-offset addressing form instead of 64-bit pointer arithmetic
+    const unsigned off = ((unsigned)(yi - 2 + kPadC) * (unsigned)pitch + (unsigned)(xi - 2 + kPadC)) * 8u;
+    const char* base = reinterpret_cast<const char*>(col);
 #pragma unroll
     for (int row = 0; row < 4; ++row) {
-      raw[row][0] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch);
-      raw[row][1] = *reinterpret_cast<const u4a8*>(r + (size_t)row * pitch + 2);
+      raw[row][0] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u));
+      raw[row][1] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u + 16u));
     }
   }
   // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
@@ -199,9 +202,10 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
     const int xi = (int)xf, yi = (int)yf;
     const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
     const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
-    const ushort4* r0 = bia + (size_t)(yi - 1 + kPadC) * pitch + (xi - 1 + kPadC);
-    const u4a8 a = *reinterpret_cast<const u4a8*>(r0);
-    const u4a8 b = *reinterpret_cast<const u4a8*>(r0 + pitch);
+    const unsigned off = ((unsigned)(yi - 1 + kPadC) * (unsigned)pitch + (unsigned)(xi - 1 + kPadC)) * 8u;
+    const char* base = reinterpret_cast<const char*>(bia);
+    const u4a8 a = *reinterpret_cast<const u4a8*>(base + off);
+    const u4a8 b = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)pitch * 8u));
     // (B, G) as one packed pair, R alone — same per-lane operations as bilerp_u16
     const v2f sbBG = trunc2(splat2(w00) * bg_of(a.x) + splat2(w01) * bg_of(a.z) + splat2(w10) * bg_of(b.x) +
                             splat2(w11) * bg_of(b.z));
@@ -398,9 +402,11 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       const int xi = (int)xf, yi = (int)yf;
       const float xw = sx - xf + 0.5f, yw = sy - yf + 0.5f;
       const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
-      const float2* r0 = V.projWarp + tab * wPlane + (size_t)(yi - 1 + kPadW) * wPitch + (xi - 1 + kPadW);
-      const f4a8 a = *reinterpret_cast<const f4a8*>(r0);
-      const f4a8 b = *reinterpret_cast<const f4a8*>(r0 + wPitch);
+      // 32-bit byte offset from the wave-uniform plane base (scalar-base addressing form)
+      const char* wbase = reinterpret_cast<const char*>(V.projWarp + tab * wPlane);
+      const unsigned woff = ((unsigned)(yi - 1 + kPadW) * (unsigned)wPitch + (unsigned)(xi - 1 + kPadW)) * 8u;
+      const f4a8 a = *reinterpret_cast<const f4a8*>(wbase + woff);
+      const f4a8 b = *reinterpret_cast<const f4a8*>(wbase + (woff + (unsigned)wPitch * 8u));
       const float wx = bilerp_f(a.x, a.z, b.x, b.z, w00, w01, w10, w11);
       const float wy = bilerp_f(a.y, a.w, b.y, b.w, w00, w01, w10, w11);
       xDstSrc = (float)((double)wx + 0.5);
