@@ -409,8 +409,10 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       const f4a8 b = *reinterpret_cast<const f4a8*>(wbase + (woff + (unsigned)wPitch * 8u));
       const float wx = bilerp_f(a.x, a.z, b.x, b.z, w00, w01, w10, w11);
       const float wy = bilerp_f(a.y, a.w, b.y, b.w, w00, w01, w10, w11);
-      xDstSrc = (float)((double)wx + 0.5);
-      yDstSrc = (float)((double)wy + 0.5);
+      // the reference adds a double literal: (float)((double)wx + 0.5). A sum of two floats rounded to
+      // double (53 >= 2 * 24 + 2 bits) and then to float equals the float sum, so one fp32 add does it
+      xDstSrc = wx + 0.5f;
+      yDstSrc = wy + 0.5f;
     }
     if (isnan(xDstSrc) || isnan(yDstSrc)) {
       continue;
