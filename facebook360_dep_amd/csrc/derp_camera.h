@@ -162,14 +162,17 @@ DERP_HD bool outside_image_circle(const Cam& c, double px, double py, double prx
 DERP_HD bool sees(const Cam& c, const D3& rig, double prx, double pry, double fx, double fy,
                   double resx, double resy, D2& pix) {
   const D3 v = {rig.x - c.pos[0], rig.y - c.pos[1], rig.z - c.pos[2]};
+  // backward().dot(v): also the camera-space z used below. forward().dot(v) is its exact negation
+  // (negating every product and the sums commutes with round-to-nearest), so it is not recomputed.
+  const double back = sum3(c.R[6] * v.x, c.R[7] * v.y, c.R[8] * v.z);
   if (c.cos_fov != -1) {
     if (c.cos_fov == 0) {
       // isBehind: backward().dot(v) >= 0
-      if (sum3(c.R[6] * v.x, c.R[7] * v.y, c.R[8] * v.z) >= 0) {
+      if (back >= 0) {
         return false;
       }
     } else {
-      const double dot = sum3((-c.R[6]) * v.x, (-c.R[7]) * v.y, (-c.R[8]) * v.z);
+      const double dot = -back;
       const double sq = sum3(v.x * v.x, v.y * v.y, v.z * v.z);
       if (dot * fabs(dot) <= c.cos_fov * fabs(c.cos_fov) * sq) {
         return false;
@@ -179,7 +182,7 @@ DERP_HD bool sees(const Cam& c, const D3& rig, double prx, double pry, double fx
   const D3 cam = {
       sum3(c.R[0] * v.x, c.R[1] * v.y, c.R[2] * v.z),
       sum3(c.R[3] * v.x, c.R[4] * v.y, c.R[5] * v.z),
-      sum3(c.R[6] * v.x, c.R[7] * v.y, c.R[8] * v.z)};
+      back};
   const D2 s = camera_to_sensor(c, cam);
   pix.x = fx * s.x + prx;
   pix.y = fy * s.y + pry;
