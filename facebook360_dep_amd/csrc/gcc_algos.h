@@ -240,8 +240,13 @@ struct GccSelect {
 static constexpr uint32_t kMinstdA = 16807u;
 static constexpr uint32_t kMinstdM = 2147483647u;
 
+// x * y mod (2^31 - 1) for x, y < 2^31 - 1. 2^31 = 1 (mod m), so the 62-bit product folds as
+// (p & m) + (p >> 31) twice, then one conditional subtraction — no 64-bit division.
 DERP_HD uint32_t minstd_mulmod(uint32_t x, uint32_t y) {
-  return (uint32_t)(((uint64_t)x * (uint64_t)y) % kMinstdM);
+  const uint64_t p = (uint64_t)x * (uint64_t)y;
+  uint64_t t = (p & kMinstdM) + (p >> 31);  // < 2^32
+  t = (t & kMinstdM) + (t >> 31);           // <= m + 1
+  return (uint32_t)(t >= kMinstdM ? t - kMinstdM : t);
 }
 // linear_congruential_engine::seed(s): s mod m, 0 -> 1 (random.tcc:114-124)
 DERP_HD uint32_t minstd_seed(int s) {
