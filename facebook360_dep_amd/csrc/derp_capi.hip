@@ -250,6 +250,12 @@ dim3 grid2d(int w, int h, int z, dim3 b) {
 }
 const dim3 kBlk2d(32, 8, 1);
 
+// k_blur3_u16: 64 x 4 threads, each a column strip of kBlurRows rows
+const dim3 kBlurBlk(64, 4, 1);
+dim3 blur_grid(int ow, int oh, int planes) {
+  return dim3((ow + 63) / 64, (oh + 4 * kBlurRows - 1) / (4 * kBlurRows), planes);
+}
+
 int flat_grid(size_t n) {
   return (int)std::min<size_t>((n + 255) / 256, 2048 * 4);
 }
@@ -502,7 +508,7 @@ int build_color_tables(derp_ctx* c, int dst0, int nd) {
     // grid.z is limited to 65535
     for (int p0 = 0; p0 < planes; p0 += 32768) {
       const int np = std::min(32768, planes - p0);
-      hipLaunchKernelGGL(k_blur3_u16, grid2d(V.W + 2 * kPadC, V.H + 2 * kPadC, np, kBlk2d), kBlk2d, 0, c->stream,
+      hipLaunchKernelGGL(k_blur3_u16, blur_grid(V.W + 2 * kPadC, V.H + 2 * kPadC, np), kBlurBlk, 0, c->stream,
                          c->projColor.as<ushort4>() + (size_t)p0 * plane, kPadC,
                          c->projBias.as<ushort4>() + (size_t)p0 * plane, kPadC, V.W, V.H, plane, plane);
       KCHECK(c);
@@ -702,7 +708,7 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   }
   {
     Span sp(c, ST_OWN_BIAS, level);
-    hipLaunchKernelGGL(k_blur3_u16, grid2d(W, H, c->S, kBlk2d), kBlk2d, 0, c->stream,
+    hipLaunchKernelGGL(k_blur3_u16, blur_grid(W, H, c->S), kBlurBlk, 0, c->stream,
                        c->pyrColor[level].as<ushort4>(), 0, c->ownBias.as<ushort4>(), 0, W, H, n, n);
     KCHECK(c);
   }

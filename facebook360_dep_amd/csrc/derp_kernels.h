@@ -564,17 +564,13 @@ __global__ void k_variance(const ushort4* __restrict__ color, int W, int H, floa
 // colorBias = cv::blur 3x3 on CV_16UC3 (DerpUtil.cpp:208-210): exact integer sum, round(sum/9).
 // Source and destination may carry replicated rings (padIn / padOut); the blur itself uses
 // BORDER_REFLECT_101 over the image interior, and ring texels repeat the clamped interior value.
-__global__ void k_blur3_u16(const ushort4* __restrict__ in, int padIn, ushort4* __restrict__ out, int padOut, int W,
-                            int H, size_t planeIn, size_t planeOut) {
-  const int p = blockIdx.z;
-  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
-  const int OW = W + 2 * padOut, OH = H + 2 * padOut;
-  if (ox >= OW || oy >= OH) {
-    return;
-  }
-  const int x = min(max(ox - padOut, 0), W - 1), y = min(max(oy - padOut, 0), H - 1);
-  const ushort4* img = in + (size_t)p * planeIn;
-  const int IW = W + 2 * padIn;
+// One thread = one column of kBlurRows consecutive output rows. Away from the borders the three
+// horizontal 3-sums of a column slide down the rows (3 loads per output instead of 9); threads whose
+// strip touches a border, where BORDER_REFLECT_101 / the ring replication change the tap pattern, take
+// the texel-by-texel form for their rows.
+constexpr int kBlurRows = 8;
+__device__ __forceinline__ ushort4 blur3_texel(const ushort4* __restrict__ img, int IW, int padIn, int W, int H, int x,
+                                               int y) {
   unsigned s0 = 0, s1 = 0, s2 = 0;
   for (int j = -1; j <= 1; ++j) {
     const int yy = reflect101(y + j, H) + padIn;
@@ -586,8 +582,51 @@ __global__ void k_blur3_u16(const ushort4* __restrict__ in, int padIn, ushort4* 
       s2 += q.z;
     }
   }
-  out[(size_t)p * planeOut + (size_t)oy * OW + ox] =
-      make_ushort4((unsigned short)((s0 + 4) / 9), (unsigned short)((s1 + 4) / 9), (unsigned short)((s2 + 4) / 9), 0);
+  return make_ushort4((unsigned short)((s0 + 4) / 9), (unsigned short)((s1 + 4) / 9), (unsigned short)((s2 + 4) / 9), 0);
+}
+__global__ void k_blur3_u16(const ushort4* __restrict__ in, int padIn, ushort4* __restrict__ out, int padOut, int W,
+                            int H, size_t planeIn, size_t planeOut) {
+  const int p = blockIdx.z;
+  const int ox = blockIdx.x * blockDim.x + threadIdx.x;
+  const int oy0 = (blockIdx.y * blockDim.y + threadIdx.y) * kBlurRows;
+  const int OW = W + 2 * padOut, OH = H + 2 * padOut;
+  if (ox >= OW || oy0 >= OH) {
+    return;
+  }
+  const ushort4* img = in + (size_t)p * planeIn;
+  ushort4* dst = out + (size_t)p * planeOut;
+  const int IW = W + 2 * padIn;
+  const int x = ox - padOut, y0 = oy0 - padOut;
+  if (x >= 1 && x <= W - 2 && y0 >= 1 && y0 + kBlurRows - 1 <= H - 2) {
+    auto hsum = [&](int y, unsigned (&h)[3]) {
+      const ushort4* r = img + (size_t)(y + padIn) * IW + (x + padIn);
+      const ushort4 a = r[-1], b = r[0], c = r[1];
+      h[0] = (unsigned)a.x + b.x + c.x;
+      h[1] = (unsigned)a.y + b.y + c.y;
+      h[2] = (unsigned)a.z + b.z + c.z;
+    };
+    unsigned hp[3], hc[3], hn[3];
+    hsum(y0 - 1, hp);
+    hsum(y0, hc);
+#pragma unroll
+    for (int r = 0; r < kBlurRows; ++r) {
+      hsum(y0 + r + 1, hn);
+      dst[(size_t)(oy0 + r) * OW + ox] =
+          make_ushort4((unsigned short)((hp[0] + hc[0] + hn[0] + 4) / 9), (unsigned short)((hp[1] + hc[1] + hn[1] + 4) / 9),
+                       (unsigned short)((hp[2] + hc[2] + hn[2] + 4) / 9), 0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        hp[c] = hc[c];
+        hc[c] = hn[c];
+      }
+    }
+    return;
+  }
+  const int xc = min(max(x, 0), W - 1);
+  for (int r = 0; r < kBlurRows && oy0 + r < OH; ++r) {
+    const int yc = min(max(y0 + r, 0), H - 1);
+    dst[(size_t)(oy0 + r) * OW + ox] = blur3_texel(img, IW, padIn, W, H, xc, yc);
+  }
 }
 
 // ----------------------------------------------------------------------------------------
