@@ -1277,10 +1277,8 @@ __global__ void __launch_bounds__(256)
   const int p = blockIdx.z;
   const int T = 16 + 2 * radius;
   const int n = T * T;
-  float* tImg = ldsTile;                  // [n]
-  float* tG0 = ldsTile + n;               // [n] x 3 guide channels (already scaled by the factor)
-  float* tG1 = ldsTile + 2 * n;
-  float* tG2 = ldsTile + 3 * n;
+  // per tile texel one 16-byte record (guide x 3 already scaled by the factor, image): one LDS read per tap
+  float4* tTex = reinterpret_cast<float4*>(ldsTile);  // [n]
   uint8_t* tMask = reinterpret_cast<uint8_t*>(ldsTile + 4 * n);
   const float* img = image + (size_t)p * planeStride;
   const uint8_t* m = mask + (size_t)p * planeStride;
@@ -1290,20 +1288,15 @@ __global__ void __launch_bounds__(256)
     const int ty = i / T, tx = i - ty * T;
     const int sx = min(max(x0 + tx, 0), W - 1), sy = min(max(y0 + ty, 0), H - 1);
     const size_t j = (size_t)sy * W + sx;
-    tImg[i] = img[j];
     tMask[i] = m[j];
     if (GUIDE_U16) {
       const ushort4 g = reinterpret_cast<const ushort4*>(guideV)[gplane + j];
       const float factor = 1 / 65535.0f;
-      tG0[i] = g.x * factor;
-      tG1[i] = g.y * factor;
-      tG2[i] = g.z * factor;
+      tTex[i] = make_float4(g.x * factor, g.y * factor, g.z * factor, img[j]);
     } else {
       const float* g = reinterpret_cast<const float*>(guideV) + (gplane + j) * 3;
       const float factor = 1 / 1.0f;
-      tG0[i] = g[0] * factor;
-      tG1[i] = g[1] * factor;
-      tG2[i] = g[2] * factor;
+      tTex[i] = make_float4(g[0] * factor, g[1] * factor, g[2] * factor, img[j]);
     }
   }
   __syncthreads();
@@ -1313,9 +1306,10 @@ __global__ void __launch_bounds__(256)
     return;
   }
   const int c = (ly + radius) * T + lx + radius;
-  float result = tImg[c];
+  const float4 centre = tTex[c];
+  float result = centre.w;
   if (tMask[c]) {
-    const float g0 = tG0[c], g1 = tG1[c], g2 = tG2[c];
+    const float g0 = centre.x, g1 = centre.y, g2 = centre.z;
     const float denom = 2.0f * (sigma * sigma);
     const double rcpDenom = 1.0 / (double)denom, rcp3 = 1.0 / 3.0;
     float sumWeight = 0.f, weightedAvg = 0.f;
@@ -1326,11 +1320,12 @@ __global__ void __launch_bounds__(256)
         if (!tMask[j]) {
           continue;
         }
-        const float d0 = g0 - tG0[j], d1 = g1 - tG1[j], d2 = g2 - tG2[j];
+        const float4 t = tTex[j];
+        const float d0 = g0 - t.x, d1 = g1 - t.y, d2 = g2 - t.z;
         const float colorDiffSq = weight0 * (d0 * d0) + weight1 * (d1 * d1) + weight2 * (d2 * d2);
         const float weight = expf_glibc(div_by_const(div_by_const(-colorDiffSq, rcp3), rcpDenom), expTab);  // (-c / 3.0f) / denom
         sumWeight += weight;
-        weightedAvg += weight * tImg[j];
+        weightedAvg += weight * t.w;
       }
     }
     if (sumWeight != 0.0f) {
