@@ -916,7 +916,7 @@ __global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__
   __syncthreads();
   // exclusive scan of 256 partials (Hillis-Steele)
   for (int off = 1; off < 256; off <<= 1) {
-    const int v = (threadIdx.x >= off) ? partial[threadIdx.x - off] : 0;
+    const int v = ((int)threadIdx.x >= off) ? partial[threadIdx.x - off] : 0;
     __syncthreads();
     partial[threadIdx.x] += v;
     __syncthreads();
