@@ -109,6 +109,7 @@ int main(int argc, char** argv) {
       cp[i] = colors[i].data();
       dp[i] = disps[i].data();
     }
+    DERP_OK(ctx, derp_rephotograph_upload(ctx, cp.data(), dp.data(), w, h));
     double frameScore[3] = {0, 0, 0};
     int used = 0;
     for (size_t i = 0; i < rig.size(); ++i) {
@@ -118,7 +119,7 @@ int main(int argc, char** argv) {
       }
       LOG_INFO("Processing " + frame + " - " + camId + "...");
       std::vector<float> rendered(n * 4);
-      DERP_OK(ctx, derp_rephotograph(ctx, (int)i, cp.data(), dp.data(), w, h, rendered.data()));
+      DERP_OK(ctx, derp_rephotograph_render(ctx, (int)i, rendered.data()));
       // reference side: own colour in [0, 1]; mask = own disparity valid (the cubemap's alpha > 0)
       std::vector<float> x(n * 3), y(n * 3);
       std::vector<uint8_t> mask(n);

@@ -118,6 +118,8 @@ struct derp_ctx {
   std::map<std::pair<int, int>, LanczosTab*> lanczos;
   std::map<std::pair<int, int>, AreaTabDev*> areaTabs;
   DevBuf fullFrame;
+  DevBuf rephotoColor, rephotoDisp;  // derp_rephotograph_upload: S planes of BGR u16 / f32 disparity
+  int rephotoW = 0, rephotoH = 0;
   DevBuf spiral;
   int spiralN = 0, spiralRadius = -1;
 
@@ -960,6 +962,8 @@ void derp_destroy(derp_ctx* c) {
     delete kv.second;
   }
   c->fullFrame.release();
+  c->rephotoColor.release();
+  c->rephotoDisp.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1544,9 +1548,8 @@ int derp_average_score(const float* score_bgr, const uint8_t* mask, int w, int h
   return 0;
 }
 
-int derp_rephotograph(derp_ctx* c, int target, const uint16_t* const* colors, const float* const* disparities, int w,
-                      int h, float* out_bgra) {
-  if (!c || !colors || !disparities || !out_bgra || w <= 0 || h <= 0 || target < 0 || target >= c->S) {
+int derp_rephotograph_upload(derp_ctx* c, const uint16_t* const* colors, const float* const* disparities, int w, int h) {
+  if (!c || !colors || !disparities || w <= 0 || h <= 0) {
     return fail(c, "bad arguments");
   }
   if ((size_t)w * h > (1u << 24) || c->S > 256) {
@@ -1554,38 +1557,58 @@ int derp_rephotograph(derp_ctx* c, int target, const uint16_t* const* colors, co
   }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)w * h;
-  DevBuf col, disp, key, out;
+  c->rephotoW = c->rephotoH = 0;
+  ALLOC(c, c->rephotoColor, (size_t)c->S * n * 6);
+  ALLOC(c, c->rephotoDisp, (size_t)c->S * n * 4);
+  for (int s = 0; s < c->S; ++s) {
+    if (!colors[s] || !disparities[s]) {
+      return fail(c, "null colour / disparity for source %d", s);
+    }
+    HIPCHK(c, hipMemcpy((char*)c->rephotoColor.p + (size_t)s * n * 6, colors[s], n * 6, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy((char*)c->rephotoDisp.p + (size_t)s * n * 4, disparities[s], n * 4, hipMemcpyHostToDevice));
+  }
+  c->rephotoW = w;
+  c->rephotoH = h;
+  return 0;
+}
+
+int derp_rephotograph_render(derp_ctx* c, int target, float* out_bgra) {
+  if (!c || !out_bgra || target < 0 || target >= c->S) {
+    return fail(c, "bad arguments");
+  }
+  if (c->rephotoW <= 0) {
+    return fail(c, "derp_rephotograph_upload has not been called");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int w = c->rephotoW, h = c->rephotoH;
+  const size_t n = (size_t)w * h;
+  DevBuf key, out;
   int rc = 0;
-  if (col.ensure((size_t)c->S * n * 6) || disp.ensure((size_t)c->S * n * 4) || key.ensure(n * 8) || out.ensure(n * 16)) {
+  if (key.ensure(n * 8) || out.ensure(n * 16)) {
     rc = fail(c, "out of device memory");
   } else {
-    for (int s = 0; s < c->S && !rc; ++s) {
-      if (s == target) {
-        continue;
-      }
-      if (!colors[s] || !disparities[s]) {
-        rc = fail(c, "null colour / disparity for source %d", s);
-        break;
-      }
-      (void)hipMemcpy((char*)col.p + (size_t)s * n * 6, colors[s], n * 6, hipMemcpyHostToDevice);
-      (void)hipMemcpy((char*)disp.p + (size_t)s * n * 4, disparities[s], n * 4, hipMemcpyHostToDevice);
-    }
-    if (!rc) {
-      (void)hipMemsetAsync(key.p, 0xff, n * 8, c->stream);
-      hipLaunchKernelGGL(k_rephoto_splat, grid2d(w, h, c->S, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), target,
-                         disp.as<float>(), w, h, key.as<unsigned long long>());
-      hipLaunchKernelGGL(k_rephoto_resolve, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), target,
-                         col.as<uint16_t>(), key.as<unsigned long long>(), w, h, out.as<float4>());
-      if (hipStreamSynchronize(c->stream) != hipSuccess ||
-          hipMemcpy(out_bgra, out.p, n * 16, hipMemcpyDeviceToHost) != hipSuccess) {
-        rc = fail(c, "HIP error in derp_rephotograph: %s", hipGetErrorString(hipGetLastError()));
-      }
+    (void)hipMemsetAsync(key.p, 0xff, n * 8, c->stream);
+    hipLaunchKernelGGL(k_rephoto_splat, grid2d(w, h, c->S, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), target,
+                       c->rephotoDisp.as<float>(), w, h, key.as<unsigned long long>());
+    hipLaunchKernelGGL(k_rephoto_resolve, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), target,
+                       c->rephotoColor.as<uint16_t>(), key.as<unsigned long long>(), w, h, out.as<float4>());
+    if (hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(out_bgra, out.p, n * 16, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error in derp_rephotograph_render: %s", hipGetErrorString(hipGetLastError()));
     }
   }
-  for (DevBuf* b : {&col, &disp, &key, &out}) {
-    b->release();
-  }
+  key.release();
+  out.release();
   return rc;
+}
+
+int derp_rephotograph(derp_ctx* c, int target, const uint16_t* const* colors, const float* const* disparities, int w,
+                      int h, float* out_bgra) {
+  if (!c || target < 0 || target >= c->S) {
+    return fail(c, "bad arguments");
+  }
+  TRY(derp_rephotograph_upload(c, colors, disparities, w, h));
+  return derp_rephotograph_render(c, target, out_bgra);
 }
 
 int derp_download_mismatch_mask(derp_ctx* c, int d, uint8_t* out) {

@@ -45,7 +45,7 @@ EXPORTS = [
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
     "derp_stage_ping_pong", "derp_stage_mismatches", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
-    "derp_ssim", "derp_average_score", "derp_rephotograph",
+    "derp_ssim", "derp_average_score", "derp_rephotograph", "derp_rephotograph_upload", "derp_rephotograph_render",
     "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",

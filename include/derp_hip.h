@@ -168,9 +168,13 @@ int derp_average_score(const float* score_bgr, const uint8_t* mask, int w, int h
 /* Camera-space stand-in for ComputeRephotographyErrors.cpp:69-189 `generateCubemaps(removeOne(i))`:
  * what the other source cameras' colour + disparity say camera `target` sees (point z-buffer + one
  * bilinear fetch; no OpenGL). colors[s] = BGR u16 [h][w][3], disparities[s] = f32 [h][w] for every
- * source camera s (entry `target` is ignored). out = BGRA float [h][w][4], alpha = covered. */
+ * source camera s. out = BGRA float [h][w][4], alpha = covered. */
 int derp_rephotograph(derp_ctx* ctx, int target, const uint16_t* const* colors, const float* const* disparities,
                       int w, int h, float* out_bgra);
+/* the same in two steps, for rendering several targets from one upload (every entry must be non-NULL) */
+int derp_rephotograph_upload(derp_ctx* ctx, const uint16_t* const* colors, const float* const* disparities, int w,
+                             int h);
+int derp_rephotograph_render(derp_ctx* ctx, int target, float* out_bgra);
 /* generateFovMasks for one destination camera at an arbitrary size (DerpUtil.cpp:259-276) */
 int derp_fov_mask(derp_ctx* ctx, int dst, int w, int h, uint8_t* out);
 /* upsampleDisparities for one camera (UpsampleDisparityLib.cpp:98-182). fg_mask / fg_mask_up /
