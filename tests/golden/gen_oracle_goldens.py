@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Freezes the oracle's output on the 'tiny' synthetic rig (4 cameras, 96x96, 3 levels) into
 tests/golden/oracle_tiny.npz: inputs are regenerated deterministically by the test; the file holds
-the expected level-0 / level-2 disparities with and without foreground masks, plus table samples.
+the expected level-0 / level-2 disparities with and without foreground masks, table samples, and the
+sibling stages (rephotography render + SSIM / NCC maps + mean score, foreground mask, layer compositing).
 Run from the repo root:  python tests/golden/gen_oracle_goldens.py"""
 import os
 import sys
@@ -35,6 +36,24 @@ def run():
     out["variance_2"] = L.variance(2)
     out["fov_3"] = L.fov_mask(3)
     out["input_color_l1_cam0"] = frame["color"][1][0]
+    # sibling stages: rephotography score, foreground masks, layer compositing
+    from oracle import oracle_lib as O
+
+    R = O.Rig(rig["cameras"]).normalize()
+    cols = frame["color"][0]
+    disps = [np.asarray(d, dtype=np.float32) for d in out["plain_l0"]]
+    rendered = O.rephotograph(R, 1, cols, disps)
+    out["rephoto_cam1"] = rendered
+    mask = (np.isfinite(disps[1]) & (disps[1] > 0)).astype(np.uint8)
+    x = cols[1].astype(np.float32) * (np.float32(1.0) / np.float32(65535.0)) * mask[..., None]
+    score = O.compute_ssim(x, rendered[..., :3], 1)
+    out["ssim_cam1"] = score
+    out["ncc_cam1_r2"] = O.compute_ssim(x, rendered[..., :3], 2, 0, 0, 1)
+    out["mssim_cam1"] = np.array(O.average_score(score, mask), dtype=np.float64)
+    frame1 = synth.make_frame(rig, sizes, frame=3, device="cpu")
+    out["fgmask_cam0"] = O.generate_foreground_mask(cols[0], frame1["color"][0][0], 1, 0.04, 4)
+    out["layers_cam0"] = O.layer_disparities(np.where(frame["masks"][0][0] == 1, disps[0], 0).astype(np.float32),
+                                             frame["bg_disp"][0][0])
     return out
 
 

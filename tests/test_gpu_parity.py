@@ -70,6 +70,63 @@ def test_level_tables(small, gpu):
     print("table elements differing from the oracle:", total)
 
 
+def test_against_committed_golden_fixture(built):
+    """The HIP path against tests/golden/oracle_tiny.npz directly (no oracle call at test time): the
+    'tiny' rig's pyramids with and without foreground masks, level-1 tables, and the sibling stages."""
+    import os
+
+    from facebook360_dep_amd import derp, synth
+
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_tiny.npz"))
+    n, res, widths = synth.config("tiny")
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    frame = synth.make_frame(rig, sizes, with_masks=True, device="cpu")
+    assert np.array_equal(frame["color"][1][0], gold["input_color_l1_cam0"])
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid(sizes, res, res)
+    g.upload_frame({"color": frame["color"]})
+    g.process_pyramid()
+    g.synchronize()
+    disps = [g.download_disparity(0, d) for d in range(n)]
+    for d in range(n):
+        assert common.compare_disparity(disps[d], gold["plain_l0"][d], TOL)[0] == 0
+        assert common.compare_disparity(g.download_disparity(2, d), gold["plain_l2"][d], TOL)[0] == 0
+    c = g.counters()
+    assert c["n_cost"] == int(gold["plain_counters"][:, 0].sum()) and c["n_pair"] == int(gold["plain_counters"][:, 1].sum())
+    g.level_begin(1)
+    g.stage("reproject_colors")
+    assert _float_equal(g.debug(1, 0, "warp"), gold["warp_1_0"]) <= 4
+    assert int((g.debug(1, 0, "color") != gold["color_1_0"]).sum()) <= 12
+    assert int((g.debug(1, 0, "bias") != gold["bias_1_0"]).sum()) <= 40
+    assert _float_equal(g.debug(0, 2, "variance"), gold["variance_2"]) == 0
+    assert np.array_equal(g.debug(3, 0, "fov"), gold["fov_3"])
+    # sibling stages on the golden disparities
+    gd = [np.asarray(x, dtype=np.float32) for x in gold["plain_l0"]]
+    rendered = g.rephotograph(1, frame["color"][0], gd)
+    assert _float_equal(rendered, gold["rephoto_cam1"]) == 0
+    mask = (np.isfinite(gd[1]) & (gd[1] > 0)).astype(np.uint8)
+    x = frame["color"][0][1].astype(np.float32) * (np.float32(1.0) / np.float32(65535.0)) * mask[..., None]
+    score = g.ssim(x, gold["rephoto_cam1"][..., :3], 1)
+    assert _float_equal(score, gold["ssim_cam1"]) == 0
+    assert _float_equal(g.ssim(x, gold["rephoto_cam1"][..., :3], 2, 0, 0, 1), gold["ncc_cam1_r2"]) == 0
+    assert derp.average_score(score, mask) == list(gold["mssim_cam1"])
+    frame1 = synth.make_frame(rig, sizes, frame=3, device="cpu")
+    assert np.array_equal(g.generate_foreground_mask(frame["color"][0][0], frame1["color"][0][0], 1, 0.04, 4),
+                          gold["fgmask_cam0"])
+    fgd = np.where(frame["masks"][0][0] == 1, gd[0], 0).astype(np.float32)
+    assert np.array_equal(g.layer_disparities(fgd, frame["bg_disp"][0][0]), gold["layers_cam0"])
+    g.close()
+    g = derp.Derp(rig["cameras"], partial_coverage=1, use_foreground_masks=1)
+    g.set_pyramid(sizes, res, res)
+    g.upload_frame(frame)
+    g.process_pyramid()
+    g.synchronize()
+    for d in range(n):
+        assert common.compare_disparity(g.download_disparity(0, d), gold["fg_l0"][d], TOL)[0] == 0
+    g.close()
+
+
 def test_cost_map(small, gpu):
     """computeCost on a random disparity field: cost and confidence."""
     level = 1
