@@ -243,7 +243,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",  # photometry in f32 over u16 texels; camera geometry in f64
+        "dtype": "f32+f64",  # photometry in f32 over u16 texels; camera geometry in f64
         "data": "synthetic",
         "config": {
             "workload": ("%s: %d-camera %dx%d synthetic rig, single frame, full %d-level pyramid"
