@@ -515,6 +515,36 @@ def test_config1_full_size_against_oracle(built):
     g.close()
 
 
+def test_config2_rig_at_512_against_oracle(built):
+    """BASELINE config 2's rig (16 cameras, Fibonacci sphere) at 512^2 with the full 8-level pyramid,
+    every level of every camera against the oracle (the largest size the oracle finishes in seconds
+    on the GPU box's host cores)."""
+    from facebook360_dep_amd import derp, synth
+
+    n, res, widths = synth.config("cfg2s")
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    frame = synth.make_frame(rig, sizes, device="cuda")
+    cnt = {}
+    ref = common.oracle_pyramid(rig, sizes, frame, res, res, counters=cnt)
+    g = derp.Derp(rig["cameras"])
+    g.set_pyramid(sizes, res, res)
+    g.upload_frame(frame)
+    g.process_pyramid()
+    g.synchronize()
+    nbad = npx = 0
+    for level in ref:
+        for d in range(n):
+            bad, rel = common.compare_disparity(g.download_disparity(level, d), ref[level][d], TOL)
+            nbad += bad
+            npx += ref[level][d].size
+    print("config-2 rig at 512^2: %d of %d pixels outside 1e-4" % (nbad, npx))
+    assert nbad <= 1e-5 * npx
+    c = g.counters()
+    assert c["n_cost"] == sum(v["n_cost"] for v in cnt.values())
+    g.close()
+
+
 def test_config5_full_size_properties(built):
     """BASELINE config 5 at full size (16 cameras, 2048^2, foreground masks + background disparity,
     then UpsampleDisparity level 1 -> level 0 with the colour guide) through properties the domain
