@@ -541,8 +541,9 @@ int run_brute_force(derp_ctx* c, int dst0, int nd) {
   const size_t n = (size_t)V.W * V.H;
   ALLOC(c, c->bruteCost, (size_t)nd * kNumDepths * n * sizeof(float));
   ALLOC(c, c->bruteConf, (size_t)nd * kNumDepths * n * sizeof(float));
-  int tilesX;
-  const int tiles = tiles_of(V.W, V.H, tilesX);
+  // 8 x 8 pixel strips over the interior (W - 2) x (H - 2) pixels, one wave each
+  const int tilesX = std::max(1, (V.W - 2 + 7) / 8), tilesY = std::max(1, (V.H - 2 + 7) / 8);
+  const int tiles = tilesX * tilesY;
   const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
   hipLaunchKernelGGL(k_brute_costs, dim3(tiles, kNumDepths, nd), dim3(DERP_COST_BLOCK), lds, c->stream, V,
                      c->bruteCost.as<float>(), c->bruteConf.as<float>(), tilesX, tiles);

@@ -798,11 +798,15 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int i = blockIdx.y;   // disparity index
   const int dl = blockIdx.z;
   const int d = V.dst0 + dl;
-  int x, y;
-  tile_pixel(blockIdx.x, tilesX, x, y);
+  // the coarsest level is small (50 x 50): interior pixels are numbered densely in 8-wide strips of
+  // 8 rows so that no lane of the grid is padding (tilesX = strips per row of strips here)
+  const int iw = V.W - 2, ih = V.H - 2;
+  const int lane = threadIdx.x & 63;
+  const int sx = (int)(blockIdx.x % (unsigned)tilesX), sy = (int)(blockIdx.x / (unsigned)tilesX);
+  const int x = 1 + sx * 8 + (lane & 7), y = 1 + sy * 8 + (lane >> 3);
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
   unsigned nCost = 0, nPair = 0;
-  if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
+  if (x <= iw && y <= ih) {
     const int own = V.dst2src[d];
     const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
     const float minDisparity = 1.0f / V.maxDepthM, maxDisparity = 1.0f / V.minDepthM;
