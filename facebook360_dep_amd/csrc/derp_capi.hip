@@ -102,9 +102,16 @@ struct derp_ctx {
 
   int numLevels = 0, widthFull = 0, heightFull = 0;
   std::vector<int> LW, LH;
-  // HBM-resident pyramid
+  // HBM-resident pyramid of the SELECTED frame slot; the other slots' pyramids are parked in `parked`
+  // (derp_set_frame_slots / derp_select_frame: several frames of one sequence resident on this GPU)
   std::vector<DevBuf> pyrColor, pyrFg, pyrBg, pyrDisp;
   std::vector<char> haveBg, haveDisp;
+  struct FrameSlot {
+    std::vector<DevBuf> pyrColor, pyrFg, pyrBg, pyrDisp;
+    std::vector<char> haveBg, haveDisp;
+  };
+  std::vector<FrameSlot> parked;  // parked[curSlot] is empty while that slot is selected
+  int curSlot = 0;
 
   // working level
   int cur = -1;
@@ -118,6 +125,7 @@ struct derp_ctx {
   std::map<std::pair<int, int>, LanczosTab*> lanczos;
   std::map<std::pair<int, int>, AreaTabDev*> areaTabs;
   DevBuf fullFrame;
+  DevBuf devMask;  // derp_dev_mask result (not a working buffer)
   DevBuf rephotoColor, rephotoDisp;  // derp_rephotograph_upload: S planes of BGR u16 / f32 disparity
   int rephotoW = 0, rephotoH = 0;
   DevBuf spiral;
@@ -600,6 +608,11 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
                        c->changed.as<uint8_t>() + (size_t)dst0 * n, n * nd);
     KCHECK(c);
   }
+  // cost / confidence now belong to ping-pong's result (+inf where every candidate was rejected): the
+  // memoised candidate must not be served from them by a later derp_stage_ping_pong call
+  if (dst0 + nd >= c->D) {
+    c->randomRanThisLevel = false;
+  }
   return 0;
 }
 
@@ -618,6 +631,7 @@ int run_mismatches(derp_ctx* c) {
     }
   }
   Span sp(c, ST_MISMATCH, L);
+  c->randomRanThisLevel = false;  // the working disparity changes: cost[] no longer matches it
   LevelView V = make_view(c, ST_MISMATCH, 0, c->D);
   const size_t n = (size_t)V.W * V.H;
   hipLaunchKernelGGL(k_mismatch, dim3((V.W + 15) / 16, (V.H + 15) / 16, c->D), dim3(256), 256 * sizeof(float) * c->S,
@@ -640,6 +654,7 @@ size_t bilateral_lds_bytes(int radius) {
 int run_bilateral(derp_ctx* c) {
   const int L = c->cur;
   Span sp(c, ST_BILATERAL, L);
+  c->randomRanThisLevel = false;  // the working disparity changes: cost[] no longer matches it
   const int W = c->LW[L], H = c->LH[L];
   const size_t n = (size_t)W * H;
   // weights passed (B, G, R) = (0.5, 1, 1) — Derp.cpp:893-896, Derp.h:44-48; sigma 0.005
@@ -656,6 +671,7 @@ int run_bilateral(derp_ctx* c) {
 int run_median(derp_ctx* c, bool fuseMaskFov) {
   const int L = c->cur;
   Span sp(c, ST_MEDIAN, L);
+  c->randomRanThisLevel = false;  // the working disparity changes: cost[] no longer matches it
   const int W = c->LW[L], H = c->LH[L];
   const size_t n = (size_t)W * H;
   hipLaunchKernelGGL(k_masked_median, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->disparity.as<float>(),
@@ -834,6 +850,55 @@ int upload_tmp(derp_ctx* c, DevBuf& buf, const T* host, size_t count) {
   return 0;
 }
 
+
+// HBM-resident pyramid of one frame (colour, fg masks, background disparity, result per level)
+int alloc_pyramid(derp_ctx* c, std::vector<DevBuf>& color, std::vector<DevBuf>& fg, std::vector<DevBuf>& bg,
+                  std::vector<DevBuf>& disp, std::vector<char>& haveBg, std::vector<char>& haveDisp) {
+  const int num_levels = c->numLevels;
+  color.resize(num_levels);
+  fg.resize(num_levels);
+  bg.resize(num_levels);
+  disp.resize(num_levels);
+  haveBg.assign(num_levels, 0);
+  haveDisp.assign(num_levels, 0);
+  for (int l = 0; l < num_levels; ++l) {
+    const size_t n = npx(c, l);
+    if (n == 0) {
+      continue;  // level not present / not needed by this run
+    }
+    ALLOC(c, color[l], n * c->S * sizeof(ushort4));
+    ALLOC(c, fg[l], n * c->S);
+    ALLOC(c, bg[l], n * c->D * sizeof(float));
+    ALLOC(c, disp[l], n * c->D * sizeof(float));
+    HIPCHK(c, hipMemsetAsync(fg[l].p, 1, n * c->S, c->stream));  // generateAllPassMasks
+    HIPCHK(c, hipMemsetAsync(bg[l].p, 0, n * c->D * sizeof(float), c->stream));
+  }
+  return 0;
+}
+
+// make `slot` the frame the pyramid members refer to
+int select_frame(derp_ctx* c, int slot) {
+  if (slot < 0 || slot >= (int)c->parked.size()) {
+    return fail(c, "frame slot %d out of range [0, %d)", slot, (int)c->parked.size());
+  }
+  if (slot == c->curSlot) {
+    return 0;
+  }
+  auto swap_with = [&](derp_ctx::FrameSlot& fs) {
+    std::swap(fs.pyrColor, c->pyrColor);
+    std::swap(fs.pyrFg, c->pyrFg);
+    std::swap(fs.pyrBg, c->pyrBg);
+    std::swap(fs.pyrDisp, c->pyrDisp);
+    std::swap(fs.haveBg, c->haveBg);
+    std::swap(fs.haveDisp, c->haveDisp);
+  };
+  swap_with(c->parked[c->curSlot]);  // park the active frame
+  swap_with(c->parked[slot]);        // activate the requested one
+  c->curSlot = slot;
+  c->cur = -1;  // working buffers belong to the previously selected frame
+  return 0;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -868,6 +933,12 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
   memset(c->accLaunch, 0, sizeof c->accLaunch);
   auto bail = [&](const std::string& m) {
     g_create_error = m;
+    for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->counters}) {
+      b->release();
+    }
+    if (c->stream) {
+      (void)hipStreamDestroy(c->stream);
+    }
     delete c;
     return 1;
   };
@@ -897,6 +968,7 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
   }
   c->S = n_src;
   c->D = n_dst;
+  c->parked.assign(1, derp_ctx::FrameSlot());
   c->camsSrcH.resize(n_src);
   c->camsDstH.resize(n_dst);
   for (int i = 0; i < n_src; ++i) {
@@ -945,6 +1017,14 @@ void derp_destroy(derp_ctx* c) {
       b.release();
     }
   }
+  for (auto& fs : c->parked) {
+    for (auto* v : {&fs.pyrColor, &fs.pyrFg, &fs.pyrBg, &fs.pyrDisp}) {
+      for (auto& b : *v) {
+        b.release();
+      }
+    }
+  }
+  c->devMask.release();
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
                     &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
                     &c->projWarp, &c->projColor, &c->projBias, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
@@ -998,25 +1078,20 @@ int derp_set_pyramid(derp_ctx* c, int num_levels, const int* widths, const int* 
   c->heightFull = height_full;
   c->LW.assign(widths, widths + num_levels);
   c->LH.assign(heights, heights + num_levels);
-  c->pyrColor.resize(num_levels);
-  c->pyrFg.resize(num_levels);
-  c->pyrBg.resize(num_levels);
-  c->pyrDisp.resize(num_levels);
-  c->haveBg.assign(num_levels, 0);
-  c->haveDisp.assign(num_levels, 0);
+  // a new geometry drops every frame slot but the selected one (their buffers have the old sizes)
+  for (auto& fs : c->parked) {
+    for (auto* v : {&fs.pyrColor, &fs.pyrFg, &fs.pyrBg, &fs.pyrDisp}) {
+      for (auto& b : *v) {
+        b.release();
+      }
+    }
+  }
+  c->parked.assign(1, derp_ctx::FrameSlot());
+  c->curSlot = 0;
+  TRY(alloc_pyramid(c, c->pyrColor, c->pyrFg, c->pyrBg, c->pyrDisp, c->haveBg, c->haveDisp));
   size_t nmax = 0;
   for (int l = 0; l < num_levels; ++l) {
-    const size_t n = npx(c, l);
-    if (n == 0) {
-      continue;  // level not present / not needed by this run
-    }
-    nmax = std::max(nmax, n);
-    ALLOC(c, c->pyrColor[l], n * c->S * sizeof(ushort4));
-    ALLOC(c, c->pyrFg[l], n * c->S);
-    ALLOC(c, c->pyrBg[l], n * c->D * sizeof(float));
-    ALLOC(c, c->pyrDisp[l], n * c->D * sizeof(float));
-    HIPCHK(c, hipMemsetAsync(c->pyrFg[l].p, 1, n * c->S, c->stream));  // generateAllPassMasks
-    HIPCHK(c, hipMemsetAsync(c->pyrBg[l].p, 0, n * c->D * sizeof(float), c->stream));
+    nmax = std::max(nmax, npx(c, l));
   }
   ALLOC(c, c->srcVar, nmax * c->S * sizeof(float));
   ALLOC(c, c->ownBias, nmax * c->S * sizeof(ushort4));
@@ -1031,6 +1106,52 @@ int derp_set_pyramid(derp_ctx* c, int num_levels, const int* widths, const int* 
   c->cur = -1;
   c->warpCachedLevel = -1;
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int derp_set_frame_slots(derp_ctx* c, int n_slots) {
+  if (!c || c->numLevels == 0) {
+    return fail(c, "derp_set_pyramid has not been called");
+  }
+  if (n_slots < 1 || n_slots > 4096) {
+    return fail(c, "n_slots %d out of range (1..4096)", n_slots);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  TRY(select_frame(c, 0));
+  for (int k = (int)c->parked.size() - 1; k >= n_slots; --k) {
+    for (auto* v : {&c->parked[k].pyrColor, &c->parked[k].pyrFg, &c->parked[k].pyrBg, &c->parked[k].pyrDisp}) {
+      for (auto& b : *v) {
+        b.release();
+      }
+    }
+  }
+  const int had = (int)c->parked.size();
+  c->parked.resize(n_slots);
+  for (int k = had; k < n_slots; ++k) {
+    derp_ctx::FrameSlot& fs = c->parked[k];
+    TRY(alloc_pyramid(c, fs.pyrColor, fs.pyrFg, fs.pyrBg, fs.pyrDisp, fs.haveBg, fs.haveDisp));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+int derp_select_frame(derp_ctx* c, int slot) {
+  if (!c || c->numLevels == 0) {
+    return fail(c, "derp_set_pyramid has not been called");
+  }
+  return select_frame(c, slot);
+}
+
+int derp_frame_slots(const derp_ctx* c, int* n_slots, int* selected) {
+  if (!c) {
+    return 1;
+  }
+  if (n_slots) {
+    *n_slots = (int)c->parked.size();
+  }
+  if (selected) {
+    *selected = c->curSlot;
+  }
   return 0;
 }
 
@@ -1800,8 +1921,8 @@ int derp_masked_median(derp_ctx* c, const float* image, const float* background,
 int derp_temporal_filter_dev(derp_ctx* c, const void* const* guides, const float* const* disps,
                              const uint8_t* const* masks, int n_frames, int w, int h, int frame_offset, float sigma,
                              int space_radius, float w0, float w1, float w2, float* out_dev) {
-  if (!c || n_frames < 1 || n_frames > 8 || frame_offset < 0 || frame_offset >= n_frames) {
-    return fail(c, "temporal window must hold 1..8 frames and contain the centre frame");
+  if (!c || n_frames < 1 || n_frames > kMaxTemporalFrames || frame_offset < 0 || frame_offset >= n_frames) {
+    return fail(c, "temporal window must hold 1..%d frames and contain the centre frame", kMaxTemporalFrames);
   }
   HIPCHK(c, hipSetDevice(c->device));
   TemporalFrames F;
@@ -1812,7 +1933,7 @@ int derp_temporal_filter_dev(derp_ctx* c, const void* const* guides, const float
     F.masks[t] = masks[t];
   }
   hipLaunchKernelGGL(k_temporal, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, F, w, h, frame_offset, sigma,
-                     space_radius, w0, w1, w2, out_dev);
+                     space_radius, w0, w1, w2, out_dev, (const int*)nullptr);
   KCHECK(c);
   return 0;
 }
@@ -1820,17 +1941,17 @@ int derp_temporal_filter_dev(derp_ctx* c, const void* const* guides, const float
 int derp_temporal_filter(derp_ctx* c, const uint16_t* const* guides, const float* const* disps,
                          const uint8_t* const* masks, int n_frames, int w, int h, int frame_offset, float sigma,
                          int space_radius, float w0, float w1, float w2, float* out) {
-  if (!c || n_frames < 1 || n_frames > 8) {
-    return fail(c, "temporal window must hold 1..8 frames");
+  if (!c || n_frames < 1 || n_frames > kMaxTemporalFrames) {
+    return fail(c, "temporal window must hold 1..%d frames", kMaxTemporalFrames);
   }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)w * h;
   std::vector<DevBuf> g4(n_frames), im(n_frames), m(n_frames);
   DevBuf g3, res;
   int rc = 0;
-  const void* gp[8];
-  const float* ip[8];
-  const uint8_t* mp[8];
+  const void* gp[kMaxTemporalFrames];
+  const float* ip[kMaxTemporalFrames];
+  const uint8_t* mp[kMaxTemporalFrames];
   do {
     if (g3.ensure(n * 6) || res.ensure(n * 4)) {
       rc = fail(c, "out of device memory");
@@ -1875,6 +1996,9 @@ int derp_temporal_filter(derp_ctx* c, const uint16_t* const* guides, const float
 
 int derp_dev_disparity(derp_ctx* c, int level, int d, float** ptr, size_t* bytes) {
   TRY(check_level(c, level));
+  if (d < 0 || d >= c->D || !ptr || !bytes) {
+    return fail(c, "bad destination index / null output");
+  }
   const size_t n = npx(c, level);
   *ptr = c->pyrDisp[level].as<float>() + (size_t)d * n;
   *bytes = n * sizeof(float);
@@ -1882,6 +2006,9 @@ int derp_dev_disparity(derp_ctx* c, int level, int d, float** ptr, size_t* bytes
 }
 int derp_dev_color(derp_ctx* c, int level, int s, void** ptr, size_t* bytes) {
   TRY(check_level(c, level));
+  if (s < 0 || s >= c->S || !ptr || !bytes) {
+    return fail(c, "bad source index / null output");
+  }
   const size_t n = npx(c, level);
   *ptr = c->pyrColor[level].as<ushort4>() + (size_t)s * n;
   *bytes = n * sizeof(ushort4);
@@ -1889,11 +2016,23 @@ int derp_dev_color(derp_ctx* c, int level, int s, void** ptr, size_t* bytes) {
 }
 int derp_dev_mask(derp_ctx* c, int level, int d, uint8_t** ptr, size_t* bytes) {
   TRY(check_level(c, level));
+  if (d < 0 || d >= c->D || !ptr || !bytes) {
+    return fail(c, "bad destination index / null output");
+  }
   HIPCHK(c, hipSetDevice(c->device));
-  // fov & fg of `level` (TemporalBilateralFilter.cpp:150-160); recomputed into the working mask buffers
-  TRY(compute_fov_and_masks(c, level));
-  const size_t n = npx(c, level);
-  *ptr = c->maskAnd.as<uint8_t>() + (size_t)d * n;
+  // fov & fg of `level` (TemporalBilateralFilter.cpp:150-160) for every destination, into a buffer of its
+  // own (never a working buffer of the level loop), complete when this call returns
+  const int W = c->LW[level], H = c->LH[level];
+  const size_t n = (size_t)W * H;
+  ALLOC(c, c->devMask, n * c->D);
+  hipLaunchKernelGGL(k_fov_mask, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), W, H,
+                     c->devMask.as<uint8_t>());
+  KCHECK(c);
+  hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), c->D), dim3(256), 0, c->stream, c->devMask.as<uint8_t>(),
+                     c->pyrFg[level].as<uint8_t>(), c->dst2src.as<int>(), 0, n, c->devMask.as<uint8_t>());
+  KCHECK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *ptr = c->devMask.as<uint8_t>() + (size_t)d * n;
   *bytes = n;
   return 0;
 }
@@ -2049,3 +2188,5 @@ float derp_host_minstd_uniform(int seed, uint64_t draw_index, float a, float b) 
 }
 
 }  // extern "C"
+
+#include "derp_sequence.h"

@@ -1744,14 +1744,17 @@ __global__ void k_bgrx_to_bgr(const ushort4* __restrict__ in, uint16_t* __restri
 // temporal joint bilateral — TemporalBilateralFilter.h:126-172 (quirks kept: accumulates the
 // CENTRE pixel of frame t, int colour difference / 65535.f, no sumWeight == 0 guard)
 // ----------------------------------------------------------------------------------------
+constexpr int kMaxTemporalFrames = 31;  // window of 2 * time_radius + 1 frames, time_radius <= 15
 struct TemporalFrames {
-  const ushort4* guides[8];
-  const float* images[8];
-  const uint8_t* masks[8];
+  const ushort4* guides[kMaxTemporalFrames];  // per frame: colour planes [S or 1][H*W]
+  const float* images[kMaxTemporalFrames];    // per frame: disparity planes [D][H*W]
+  const uint8_t* masks[kMaxTemporalFrames];   // per frame: fov & fg planes [D][H*W]
   int n;
 };
+// blockIdx.z = destination camera d: disparity / mask plane d, colour plane dst2src[d] (plane 0 when
+// dst2src is null: the single-camera entry point)
 __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, float sigma, int radius, float weight0,
-                           float weight1, float weight2, float* __restrict__ out) {
+                           float weight1, float weight2, float* __restrict__ out, const int* __restrict__ dst2src) {
   __shared__ unsigned long long expTab[32];
   {
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
@@ -1764,26 +1767,30 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
   if (x >= W || y >= H) {
     return;
   }
+  const size_t n = (size_t)W * H;
+  const size_t pd = (size_t)blockIdx.z * n, pg = dst2src ? (size_t)dst2src[blockIdx.z] * n : 0;
   const size_t idx = (size_t)y * W + x;
-  if (!F.masks[frameOffset][idx]) {
-    out[idx] = F.images[frameOffset][idx];
+  if (!F.masks[frameOffset][pd + idx]) {
+    out[pd + idx] = F.images[frameOffset][pd + idx];
     return;
   }
-  const ushort4 ref = F.guides[frameOffset][idx];
+  const ushort4 ref = F.guides[frameOffset][pg + idx];
   const float sig2 = sigma * sigma;
   const double rcpSig2 = 1.0 / (double)sig2;
   float weightedSumPix = 0.f, sumWeight = 0.f;
   for (int t = 0; t < F.n; ++t) {
-    const float centre = F.images[t][idx];
+    const float centre = F.images[t][pd + idx];
+    const uint8_t* __restrict__ mask = F.masks[t] + pd;
+    const ushort4* __restrict__ guide = F.guides[t] + pg;
     for (int u = -radius; u <= radius; ++u) {
       const int sx = min(max(x + u, 0), W - 1);
       for (int v = -radius; v <= radius; ++v) {
         const int sy = min(max(y + v, 0), H - 1);
         const size_t j = (size_t)sy * W + sx;
-        if (!F.masks[t][j]) {
+        if (!mask[j]) {
           continue;
         }
-        const ushort4 sc = F.guides[t][j];
+        const ushort4 sc = guide[j];
         const float e0 = (float)((int)ref.x - (int)sc.x) / 65535.0f;
         const float e1 = (float)((int)ref.y - (int)sc.y) / 65535.0f;
         const float e2 = (float)((int)ref.z - (int)sc.z) / 65535.0f;
@@ -1794,7 +1801,7 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
       }
     }
   }
-  out[idx] = weightedSumPix / sumWeight;
+  out[pd + idx] = weightedSumPix / sumWeight;
 }
 
 // ----------------------------------------------------------------------------------------

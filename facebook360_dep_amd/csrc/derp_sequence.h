@@ -1,0 +1,735 @@
+// Sequence driver: the per-level barrier schedule of the reference's render pipeline
+// (scripts/render/pipeline.py:364-408) for the frames of a sequence sharded over GPUs.
+//
+//   for level L, coarse -> fine:
+//     DerpCLI(level L) on every frame                              -> derp_seq_level_compute
+//     TemporalBilateralFilter(level L) over [t - R, t + R]         -> derp_seq_level_exchange (halo
+//        frames' raw level disparity, point to point) + derp_seq_level_filter
+//     "Transfer": the filtered level overwrites disparity_levels/L -> end of derp_seq_level_filter
+//
+// One process per GPU, one derp_seq per process. A rank owns a set of frames (block partition like
+// render.py:169-175's frame chunks, or cyclic t mod G), each resident in a frame slot of the context.
+// The only data that crosses ranks inside the level loop is the raw level-L disparity of the frames a
+// neighbour's window reaches into (TemporalBilateralFilter.cpp:96-119,139-160); the colour guides and
+// foreground masks of those halo frames are inputs and move once (derp_seq_exchange_inputs).
+// The frame-outer order cannot be used with the temporal filter on: level L of frame t is seeded by the
+// FILTERED level L+1, which needs raw level L+1 of frames t +- R, which ... — the dependency cone widens
+// by R frames per level, so every frame must finish level L before any frame starts level L-1.
+//
+// Transports: RCCL ncclSend/ncclRecv on the context's own stream (librccl is dlopen-ed on first use;
+// no torch in the loop), same-process loopback (several ranks emulated on one GPU: tests), or external
+// (the caller moves the buffers derp_seq_buffer names: torch.distributed / gloo tests).
+// Included by derp_capi.hip (one translation unit).
+#pragma once
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+namespace {
+
+// ---- host-only plan ---------------------------------------------------------------------------
+void seq_window(int t, int first, int last, int radius, int* lo, int* hi) {
+  // populateMinMaxFrame (TemporalBilateralFilter.cpp:96-119): the frames of [t - R, t + R] that exist,
+  // i.e. the window clamped to the sequence (pipeline.py:344-362 ships exactly chunk +- R to a worker)
+  *lo = std::max(first, t - radius);
+  *hi = std::min(last, t + radius);
+}
+
+int seq_owner(int first, int last, int world, int policy, int frame) {
+  const int F = last - first + 1, i = frame - first;
+  if (i < 0 || i >= F || world < 1) {
+    return -1;
+  }
+  if (policy == DERP_SEQ_CYCLIC) {
+    return i % world;
+  }
+  // balanced contiguous chunks: the first F % world ranks own one frame more
+  const int q = F / world, r = F % world;
+  const int big = r * (q + 1);
+  return i < big ? i / (q + 1) : r + (q ? (i - big) / q : 0);
+}
+
+std::vector<derp_seq_transfer> seq_plan(int first, int last, int world, int radius, int policy) {
+  std::vector<derp_seq_transfer> out;
+  for (int t = first; t <= last; ++t) {  // frame t goes to the owner of every frame whose window holds t
+    const int from = seq_owner(first, last, world, policy, t);
+    std::vector<char> sent(world, 0);
+    int lo, hi;
+    seq_window(t, first, last, radius, &lo, &hi);  // |u - t| <= R is symmetric: same range
+    for (int u = lo; u <= hi; ++u) {
+      const int to = seq_owner(first, last, world, policy, u);
+      if (to != from) {
+        sent[to] = 1;
+      }
+    }
+    for (int to = 0; to < world; ++to) {  // ascending (frame, to): one global order for every rank
+      if (sent[to]) {
+        out.push_back({t, from, to});
+      }
+    }
+  }
+  return out;
+}
+
+// ---- RCCL, bound at run time ---------------------------------------------------------------------
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+RcclApi* rccl_api() {
+  static RcclApi api;
+  if (api.lib || !api.error.empty()) {
+    return &api;
+  }
+  // by soname first: a process that already carries an RCCL (PyTorch-ROCm bundles one) must keep using it
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) {
+      break;
+    }
+  }
+  if (!api.lib) {
+    api.error = std::string("cannot load librccl: ") + dlerror();
+    return &api;
+  }
+  auto sym = [&](const char* n) {
+    void* p = dlsym(api.lib, n);
+    if (!p && api.error.empty()) {
+      api.error = std::string("librccl lacks ") + n;
+    }
+    return p;
+  };
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+  api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+  api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!api.error.empty()) {
+    api.lib = nullptr;
+  }
+  return &api;
+}
+
+enum { SEQ_NONE = 0, SEQ_LOOPBACK = 1, SEQ_RCCL = 2, SEQ_EXTERNAL = 3 };
+
+}  // namespace
+
+struct derp_seq {
+  derp_ctx* c = nullptr;
+  int first = 0, last = 0, rank = 0, world = 1;
+  derp_seq_options opt;
+  std::vector<int> owned, halo;                 // frame numbers, ascending
+  std::vector<derp_seq_transfer> plan;          // every rank's transfers, in one global order
+  // halo frames' data: [halo index][level]
+  std::vector<std::vector<DevBuf>> haloColor, haloFg, haloDisp;
+  std::vector<DevBuf> filtered;                 // [owned index]: [D][n_level] of the level being filtered
+  DevBuf fov, winMask;                          // fov [D][n]; window masks [2R+1][D][n] (temporal masking only)
+  int transport = SEQ_NONE;
+  std::vector<derp_seq*> peers;
+  ncclComm_t comm = nullptr;
+  unsigned long long bytesSent = 0, bytesRecv = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> exchangeSpans;
+  double exchangeMs = 0;
+  int levelReady = -1;                          // level whose compute finished and whose filter has not run yet
+};
+
+namespace {
+
+int owned_index(const derp_seq* q, int frame) {
+  auto it = std::lower_bound(q->owned.begin(), q->owned.end(), frame);
+  return it != q->owned.end() && *it == frame ? (int)(it - q->owned.begin()) : -1;
+}
+int halo_index(const derp_seq* q, int frame) {
+  auto it = std::lower_bound(q->halo.begin(), q->halo.end(), frame);
+  return it != q->halo.end() && *it == frame ? (int)(it - q->halo.begin()) : -1;
+}
+
+// pyramid buffers of a frame slot whether it is selected or parked
+struct SlotView {
+  std::vector<DevBuf>*color, *fg, *disp;
+  std::vector<char>* haveDisp;
+};
+SlotView slot_view(derp_ctx* c, int slot) {
+  if (slot == c->curSlot) {
+    return {&c->pyrColor, &c->pyrFg, &c->pyrDisp, &c->haveDisp};
+  }
+  derp_ctx::FrameSlot& fs = c->parked[slot];
+  return {&fs.pyrColor, &fs.pyrFg, &fs.pyrDisp, &fs.haveDisp};
+}
+
+// kind: 0 colour pyramid level (ushort4 [S][n]), 1 fg mask (u8 [S][n]), 2 level disparity (f32 [D][n])
+int seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, size_t* bytes) {
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  if (kind < 0 || kind > 2) {
+    return fail(c, "unknown buffer kind %d", kind);
+  }
+  const size_t n = npx(c, level);
+  const size_t sz = kind == 0 ? n * c->S * sizeof(ushort4) : kind == 1 ? n * c->S : n * c->D * sizeof(float);
+  DevBuf* b = nullptr;
+  const int oi = owned_index(q, frame);
+  if (oi >= 0) {
+    SlotView v = slot_view(c, oi);
+    b = kind == 0 ? &(*v.color)[level] : kind == 1 ? &(*v.fg)[level] : &(*v.disp)[level];
+  } else {
+    const int hi = halo_index(q, frame);
+    if (hi < 0) {
+      return fail(c, "frame %d is neither owned by rank %d nor in its temporal halo", frame, q->rank);
+    }
+    b = kind == 0 ? &q->haloColor[hi][level] : kind == 1 ? &q->haloFg[hi][level] : &q->haloDisp[hi][level];
+    if (b->bytes < sz) {
+      return fail(c, "halo buffer of frame %d level %d kind %d was not allocated", frame, level, kind);
+    }
+  }
+  *ptr = b->p;
+  *bytes = sz;
+  return 0;
+}
+
+#define NCCLCHK(c, api, expr)                                                                    \
+  do {                                                                                           \
+    ncclResult_t r_ = (expr);                                                                    \
+    if (r_ != ncclSuccess) {                                                                     \
+      return fail(c, "RCCL error %s at %s:%d (%s)", (api)->GetErrorString(r_), __FILE__, __LINE__, #expr); \
+    }                                                                                            \
+  } while (0)
+
+// move buffers of `kind` at `level` along the plan (this rank's sends and receives)
+int seq_exchange(derp_seq* q, int level, int kind) {
+  derp_ctx* c = q->c;
+  if (q->world == 1 || q->transport == SEQ_EXTERNAL) {
+    return 0;
+  }
+  if (q->transport == SEQ_NONE) {
+    return fail(c, "derp_seq: world size %d but no transport attached (rccl / loopback / external)", q->world);
+  }
+  hipEvent_t ea = nullptr, eb = nullptr;
+  HIPCHK(c, hipEventCreate(&ea));
+  HIPCHK(c, hipEventCreate(&eb));
+  HIPCHK(c, hipEventRecord(ea, c->stream));
+  if (q->transport == SEQ_RCCL) {
+    RcclApi* api = rccl_api();
+    NCCLCHK(c, api, api->GroupStart());
+    for (const derp_seq_transfer& tr : q->plan) {
+      void* p;
+      size_t bytes;
+      if (tr.from_rank == q->rank) {
+        TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
+        NCCLCHK(c, api, api->Send(p, bytes, ncclUint8, tr.to_rank, q->comm, c->stream));
+        q->bytesSent += bytes;
+      } else if (tr.to_rank == q->rank) {
+        TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
+        NCCLCHK(c, api, api->Recv(p, bytes, ncclUint8, tr.from_rank, q->comm, c->stream));
+        q->bytesRecv += bytes;
+      }
+    }
+    NCCLCHK(c, api, api->GroupEnd());
+  } else {  // loopback: pull from the peer contexts of this process
+    std::vector<char> synced(q->world, 0);
+    for (const derp_seq_transfer& tr : q->plan) {
+      if (tr.from_rank == q->rank) {
+        void* p;
+        size_t bytes;
+        TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
+        q->bytesSent += bytes;
+      }
+      if (tr.to_rank != q->rank) {
+        continue;
+      }
+      derp_seq* peer = q->peers[tr.from_rank];
+      if (!synced[tr.from_rank]) {
+        HIPCHK(c, hipStreamSynchronize(peer->c->stream));
+        synced[tr.from_rank] = 1;
+      }
+      void *src, *dst;
+      size_t bs, bd;
+      if (seq_buffer(peer, tr.frame, level, kind, &src, &bs)) {
+        return fail(c, "loopback peer %d: %s", tr.from_rank, peer->c->err.c_str());
+      }
+      TRY(seq_buffer(q, tr.frame, level, kind, &dst, &bd));
+      HIPCHK(c, hipMemcpyAsync(dst, src, bd, hipMemcpyDeviceToDevice, c->stream));
+      q->bytesRecv += bd;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // pulls are complete before any peer overwrites its level
+  }
+  HIPCHK(c, hipEventRecord(eb, c->stream));
+  q->exchangeSpans.push_back({ea, eb});
+  return 0;
+}
+
+void seq_drain_spans(derp_seq* q) {
+  for (auto& s : q->exchangeSpans) {
+    (void)hipEventSynchronize(s.second);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s.first, s.second);
+    q->exchangeMs += ms;
+    (void)hipEventDestroy(s.first);
+    (void)hipEventDestroy(s.second);
+  }
+  q->exchangeSpans.clear();
+}
+
+int temporal_space_radius(const derp_seq* q, int level) {
+  // TemporalBilateralFilter.cpp:164-168: max(ceil(kTemporalSpaceRadiusMax * 0.9^level), kTemporalSpaceRadiusMin)
+  if (q->opt.space_radius != -1) {
+    return q->opt.space_radius;
+  }
+  const float scale = std::pow(0.9f, level);
+  return (int)std::max(std::ceil(1 * scale), float(1));
+}
+
+}  // namespace
+
+extern "C" {
+
+void derp_seq_options_default(derp_seq_options* o) {
+  o->time_radius = 2;         // --time_radius   TemporalBilateralFilter.cpp:54
+  o->sigma = 0.01f;           // --sigma         :51
+  o->weight_b = 0.5f;         // --weight_b      :57
+  o->weight_g = 1.0f;         // --weight_g      :58
+  o->weight_r = 1.0f;         // --weight_r      :59 (declared, never read: the call passes b, g, b — :176-178)
+  o->space_radius = -1;       // --space_radius  :52
+  o->use_foreground_masks = 0;  // pipeline.py:386 do_temporal_masking
+  o->partition = DERP_SEQ_BLOCK;
+  o->do_temporal_filter = 1;  // pipeline.py:378
+}
+
+void derp_seq_window(int frame, int first, int last, int time_radius, int* lo, int* hi) {
+  int a, b;
+  seq_window(frame, first, last, time_radius, &a, &b);
+  if (lo) {
+    *lo = a;
+  }
+  if (hi) {
+    *hi = b;
+  }
+}
+
+int derp_seq_owner(int first, int last, int world, int partition, int frame) {
+  return seq_owner(first, last, world, partition, frame);
+}
+
+int derp_seq_plan(int first, int last, int world, int time_radius, int partition, derp_seq_transfer* out, int cap) {
+  if (last < first || world < 1 || time_radius < 0) {
+    return -1;
+  }
+  const std::vector<derp_seq_transfer> p = seq_plan(first, last, world, time_radius, partition);
+  if (out) {
+    for (int i = 0; i < (int)p.size() && i < cap; ++i) {
+      out[i] = p[i];
+    }
+  }
+  return (int)p.size();
+}
+
+int derp_rccl_unique_id(void* out, size_t cap) {
+  RcclApi* api = rccl_api();
+  if (!api->lib || !out || cap < sizeof(ncclUniqueId)) {
+    return 1;
+  }
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) {
+    return 1;
+  }
+  memcpy(out, &id, sizeof id);
+  return 0;
+}
+
+int derp_seq_create(derp_seq** out, derp_ctx* c, int first, int last, int rank, int world, const derp_seq_options* opt) {
+  if (!out || !c) {
+    return 1;
+  }
+  *out = nullptr;
+  if (c->numLevels == 0) {
+    return fail(c, "derp_set_pyramid has not been called");
+  }
+  if (last < first || world < 1 || rank < 0 || rank >= world) {
+    return fail(c, "bad sequence geometry: frames %d..%d, rank %d of %d", first, last, rank, world);
+  }
+  derp_seq* q = new derp_seq;
+  q->c = c;
+  q->first = first;
+  q->last = last;
+  q->rank = rank;
+  q->world = world;
+  if (opt) {
+    q->opt = *opt;
+  } else {
+    derp_seq_options_default(&q->opt);
+  }
+  auto bail = [&](int rc) {
+    derp_seq_destroy(q);
+    return rc;
+  };
+  if (q->opt.time_radius < 0 || 2 * q->opt.time_radius + 1 > kMaxTemporalFrames) {
+    return bail(fail(c, "time_radius %d out of range (0..%d)", q->opt.time_radius, (kMaxTemporalFrames - 1) / 2));
+  }
+  if (!q->opt.do_temporal_filter) {
+    q->opt.time_radius = 0;  // no window, no halo, no exchange: replicas
+  }
+  for (int t = first; t <= last; ++t) {
+    if (seq_owner(first, last, world, q->opt.partition, t) == rank) {
+      q->owned.push_back(t);
+    }
+  }
+  q->plan = seq_plan(first, last, world, q->opt.time_radius, q->opt.partition);
+  for (const derp_seq_transfer& tr : q->plan) {
+    if (tr.to_rank == rank) {
+      q->halo.push_back(tr.frame);  // plan is ordered by frame, one entry per (frame, to)
+    }
+  }
+  if (hipSetDevice(c->device) != hipSuccess) {
+    return bail(fail(c, "hipSetDevice failed"));
+  }
+  if (derp_set_frame_slots(c, std::max<int>(1, (int)q->owned.size()))) {
+    return bail(1);
+  }
+  const int nl = c->numLevels;
+  q->haloColor.assign(q->halo.size(), std::vector<DevBuf>(nl));
+  q->haloFg.assign(q->halo.size(), std::vector<DevBuf>(nl));
+  q->haloDisp.assign(q->halo.size(), std::vector<DevBuf>(nl));
+  size_t nmax = 0;
+  for (int l = 0; l < nl; ++l) {
+    const size_t n = npx(c, l);
+    nmax = std::max(nmax, n);
+    if (n == 0) {
+      continue;
+    }
+    for (size_t h = 0; h < q->halo.size(); ++h) {
+      if (q->haloColor[h][l].ensure(n * c->S * sizeof(ushort4)) || q->haloDisp[h][l].ensure(n * c->D * sizeof(float)) ||
+          (q->opt.use_foreground_masks && q->haloFg[h][l].ensure(n * c->S))) {
+        return bail(fail(c, "out of device memory allocating the temporal halo (frame %d, level %d)", q->halo[h], l));
+      }
+    }
+  }
+  q->filtered.resize(q->owned.size());
+  for (auto& b : q->filtered) {
+    if (b.ensure(nmax * c->D * sizeof(float))) {
+      return bail(fail(c, "out of device memory allocating the filtered level"));
+    }
+  }
+  if (q->fov.ensure(nmax * c->D) ||
+      (q->opt.use_foreground_masks && q->winMask.ensure((size_t)(2 * q->opt.time_radius + 1) * nmax * c->D))) {
+    return bail(fail(c, "out of device memory allocating the temporal masks"));
+  }
+  *out = q;
+  return 0;
+}
+
+void derp_seq_destroy(derp_seq* q) {
+  if (!q) {
+    return;
+  }
+  if (q->c) {
+    (void)hipSetDevice(q->c->device);
+    (void)hipStreamSynchronize(q->c->stream);
+  }
+  seq_drain_spans(q);
+  if (q->comm) {
+    (void)rccl_api()->CommDestroy(q->comm);
+  }
+  for (auto* vv : {&q->haloColor, &q->haloFg, &q->haloDisp}) {
+    for (auto& v : *vv) {
+      for (auto& b : v) {
+        b.release();
+      }
+    }
+  }
+  for (auto& b : q->filtered) {
+    b.release();
+  }
+  q->fov.release();
+  q->winMask.release();
+  delete q;
+}
+
+int derp_seq_counts(const derp_seq* q, int* n_owned, int* n_halo) {
+  if (!q) {
+    return 1;
+  }
+  if (n_owned) {
+    *n_owned = (int)q->owned.size();
+  }
+  if (n_halo) {
+    *n_halo = (int)q->halo.size();
+  }
+  return 0;
+}
+
+int derp_seq_frames(const derp_seq* q, int halo, int* frames, int cap) {
+  if (!q || !frames) {
+    return 1;
+  }
+  const std::vector<int>& v = halo ? q->halo : q->owned;
+  for (int i = 0; i < (int)v.size() && i < cap; ++i) {
+    frames[i] = v[i];
+  }
+  return 0;
+}
+
+int derp_seq_frame_slot(const derp_seq* q, int frame) {
+  return q ? owned_index(q, frame) : -1;
+}
+
+int derp_seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, size_t* bytes) {
+  if (!q || !ptr || !bytes) {
+    return 1;
+  }
+  return seq_buffer(q, frame, level, kind, ptr, bytes);
+}
+
+int derp_seq_attach_loopback(derp_seq* q, derp_seq* const* peers, int n) {
+  if (!q || !peers || n != q->world) {
+    return q ? fail(q->c, "loopback needs one derp_seq per rank (%d given, world %d)", n, q->world) : 1;
+  }
+  q->peers.assign(peers, peers + n);
+  if (q->peers[q->rank] != q) {
+    return fail(q->c, "peers[%d] must be this rank's own derp_seq", q->rank);
+  }
+  q->transport = SEQ_LOOPBACK;
+  return 0;
+}
+
+int derp_seq_attach_external(derp_seq* q) {
+  if (!q) {
+    return 1;
+  }
+  q->transport = SEQ_EXTERNAL;
+  return 0;
+}
+
+int derp_seq_attach_rccl(derp_seq* q, const void* unique_id, size_t bytes) {
+  if (!q || !unique_id || bytes < sizeof(ncclUniqueId)) {
+    return q ? fail(q->c, "derp_seq_attach_rccl needs the %zu-byte id from derp_rccl_unique_id", sizeof(ncclUniqueId)) : 1;
+  }
+  derp_ctx* c = q->c;
+  RcclApi* api = rccl_api();
+  if (!api->lib) {
+    return fail(c, "%s", api->error.c_str());
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof id);
+  NCCLCHK(c, api, api->CommInitRank(&q->comm, q->world, id, q->rank));
+  q->transport = SEQ_RCCL;
+  return 0;
+}
+
+// one ring step over the attached transport: every rank sends `words` 32-bit words to rank + 1 and
+// checks what rank - 1 sent (transport self-test; world 1 sends to itself inside one group)
+int derp_seq_selftest(derp_seq* q, int words) {
+  if (!q || words < 1) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  if (q->transport != SEQ_RCCL) {
+    return fail(c, "derp_seq_selftest exercises the RCCL transport; attach it first");
+  }
+  RcclApi* api = rccl_api();
+  HIPCHK(c, hipSetDevice(c->device));
+  DevBuf a, b;
+  int rc = 0;
+  const size_t bytes = (size_t)words * 4;
+  std::vector<uint32_t> h(words);
+  const int next = (q->rank + 1) % q->world, prev = (q->rank + q->world - 1) % q->world;
+  for (int i = 0; i < words; ++i) {
+    h[i] = 0x9e3779b9u * (uint32_t)(i + 1) + (uint32_t)q->rank;
+  }
+  if (a.ensure(bytes) || b.ensure(bytes)) {
+    rc = fail(c, "out of device memory");
+  } else if (hipMemcpyAsync(a.p, h.data(), bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+             hipMemsetAsync(b.p, 0, bytes, c->stream) != hipSuccess) {
+    rc = fail(c, "HIP error staging the self-test");
+  } else {
+    ncclResult_t r = api->GroupStart();
+    if (r == ncclSuccess) {
+      r = api->Send(a.p, bytes, ncclUint8, next, q->comm, c->stream);
+    }
+    if (r == ncclSuccess) {
+      r = api->Recv(b.p, bytes, ncclUint8, prev, q->comm, c->stream);
+    }
+    const ncclResult_t e = api->GroupEnd();
+    if (r == ncclSuccess) {
+      r = e;
+    }
+    std::vector<uint32_t> got(words);
+    if (r != ncclSuccess) {
+      rc = fail(c, "RCCL self-test: %s", api->GetErrorString(r));
+    } else if (hipStreamSynchronize(c->stream) != hipSuccess ||
+               hipMemcpy(got.data(), b.p, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+      rc = fail(c, "HIP error reading the self-test back: %s", hipGetErrorString(hipGetLastError()));
+    } else {
+      for (int i = 0; i < words && !rc; ++i) {
+        if (got[i] != 0x9e3779b9u * (uint32_t)(i + 1) + (uint32_t)prev) {
+          rc = fail(c, "RCCL self-test: word %d from rank %d is %08x", i, prev, got[i]);
+        }
+      }
+    }
+  }
+  a.release();
+  b.release();
+  return rc;
+}
+
+int derp_seq_exchange_inputs(derp_seq* q) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int l = 0; l < c->numLevels; ++l) {
+    if (npx(c, l) == 0) {
+      continue;
+    }
+    TRY(seq_exchange(q, l, 0));
+    if (q->opt.use_foreground_masks) {
+      TRY(seq_exchange(q, l, 1));
+    }
+  }
+  return 0;
+}
+
+int derp_seq_level_compute(derp_seq* q, int level) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  for (int k = 0; k < (int)q->owned.size(); ++k) {
+    TRY(select_frame(c, k));
+    TRY(process_level(c, level));
+  }
+  q->levelReady = level;
+  return 0;
+}
+
+int derp_seq_level_exchange(derp_seq* q, int level) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  if (!q->opt.do_temporal_filter) {
+    return 0;
+  }
+  return seq_exchange(q, level, 2);
+}
+
+int derp_seq_level_filter(derp_seq* q, int level) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  TRY(check_level(c, level));
+  if (!q->opt.do_temporal_filter) {
+    return 0;
+  }
+  const int W = c->LW[level], H = c->LH[level];
+  const size_t n = (size_t)W * H;
+  hipLaunchKernelGGL(k_fov_mask, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), W, H,
+                     q->fov.as<uint8_t>());
+  KCHECK(c);
+  const int radius = temporal_space_radius(q, level);
+  for (int k = 0; k < (int)q->owned.size(); ++k) {
+    const int t = q->owned[k];
+    int lo, hi;
+    seq_window(t, q->first, q->last, q->opt.time_radius, &lo, &hi);
+    TemporalFrames F;
+    F.n = hi - lo + 1;
+    for (int u = lo; u <= hi; ++u) {
+      void *pc, *pd, *pm;
+      size_t b;
+      TRY(seq_buffer(q, u, level, 0, &pc, &b));
+      TRY(seq_buffer(q, u, level, 2, &pd, &b));
+      if (q->opt.use_foreground_masks) {  // mask = fg & fov of each frame (TemporalBilateralFilter.cpp:150-160)
+        TRY(seq_buffer(q, u, level, 1, &pm, &b));
+        uint8_t* wm = q->winMask.as<uint8_t>() + (size_t)(u - lo) * n * c->D;
+        hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), c->D), dim3(256), 0, c->stream, q->fov.as<uint8_t>(),
+                           (const uint8_t*)pm, c->dst2src.as<int>(), 0, n, wm);
+        KCHECK(c);
+        pm = wm;
+      } else {
+        pm = q->fov.p;  // generateAllPassMasks & fov
+      }
+      F.guides[u - lo] = reinterpret_cast<const ushort4*>(pc);
+      F.images[u - lo] = reinterpret_cast<const float*>(pd);
+      F.masks[u - lo] = reinterpret_cast<const uint8_t*>(pm);
+    }
+    // weights (b, g, b): the reference passes FLAGS_weight_b for the third channel (TemporalBilateralFilter.cpp:176-178)
+    hipLaunchKernelGGL(k_temporal, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, F, W, H, t - lo, q->opt.sigma,
+                       radius, q->opt.weight_b, q->opt.weight_g, q->opt.weight_b, q->filtered[k].as<float>(),
+                       c->dst2src.as<int>());
+    KCHECK(c);
+  }
+  // "Transfer" (pipeline.py:397-408): every owned frame is filtered before any raw level is overwritten
+  for (int k = 0; k < (int)q->owned.size(); ++k) {
+    SlotView v = slot_view(c, k);
+    HIPCHK(c, hipMemcpyAsync((*v.disp)[level].p, q->filtered[k].p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice,
+                             c->stream));
+  }
+  q->levelReady = -1;
+  return 0;
+}
+
+int derp_seq_run(derp_seq* q, int level_start, int level_end_) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  if (level_start < level_end_) {
+    return fail(c, "Check failed: level_start >= level_end (%d vs %d)", level_start, level_end_);
+  }
+  if (q->world > 1 && q->transport != SEQ_RCCL) {
+    return fail(c, "derp_seq_run drives all three phases itself and needs the RCCL transport; with loopback / "
+                   "external transports call derp_seq_level_compute / _exchange / _filter per level");
+  }
+  for (int level = level_start; level >= level_end_; --level) {
+    TRY(derp_seq_level_compute(q, level));
+    TRY(derp_seq_level_exchange(q, level));
+    TRY(derp_seq_level_filter(q, level));
+  }
+  return 0;
+}
+
+int derp_seq_stats(derp_seq* q, uint64_t* bytes_sent, uint64_t* bytes_received, double* exchange_ms) {
+  if (!q) {
+    return 1;
+  }
+  HIPCHK(q->c, hipStreamSynchronize(q->c->stream));
+  seq_drain_spans(q);
+  if (bytes_sent) {
+    *bytes_sent = q->bytesSent;
+  }
+  if (bytes_received) {
+    *bytes_received = q->bytesRecv;
+  }
+  if (exchange_ms) {
+    *exchange_ms = q->exchangeMs;
+  }
+  return 0;
+}
+
+int derp_seq_stats_reset(derp_seq* q) {
+  if (!q) {
+    return 1;
+  }
+  HIPCHK(q->c, hipStreamSynchronize(q->c->stream));
+  seq_drain_spans(q);
+  q->bytesSent = q->bytesRecv = 0;
+  q->exchangeMs = 0;
+  return 0;
+}
+
+}  // extern "C"

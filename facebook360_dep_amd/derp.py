@@ -16,6 +16,18 @@ STAGES = ["fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reprojec
           "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov"]
 
 
+class SeqOptions(C.Structure):
+    _fields_ = [
+        ("time_radius", C.c_int32), ("sigma", C.c_float), ("weight_b", C.c_float), ("weight_g", C.c_float),
+        ("weight_r", C.c_float), ("space_radius", C.c_int32), ("use_foreground_masks", C.c_int32),
+        ("partition", C.c_int32), ("do_temporal_filter", C.c_int32),
+    ]
+
+
+class SeqTransfer(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("from_rank", C.c_int32), ("to_rank", C.c_int32)]
+
+
 class CameraDesc(C.Structure):
     _fields_ = [
         ("type", C.c_int32), ("has_principal", C.c_int32), ("has_distortion", C.c_int32), ("has_fov", C.c_int32),
@@ -50,6 +62,12 @@ EXPORTS = [
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
     "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
+    "derp_set_frame_slots", "derp_select_frame", "derp_frame_slots",
+    "derp_seq_options_default", "derp_seq_window", "derp_seq_owner", "derp_seq_plan", "derp_seq_create", "derp_seq_destroy",
+    "derp_seq_counts", "derp_seq_frames", "derp_seq_frame_slot", "derp_seq_buffer", "derp_rccl_unique_id",
+    "derp_seq_attach_rccl", "derp_seq_attach_loopback", "derp_seq_attach_external", "derp_seq_selftest",
+    "derp_seq_exchange_inputs", "derp_seq_level_compute", "derp_seq_level_exchange", "derp_seq_level_filter",
+    "derp_seq_run", "derp_seq_stats", "derp_seq_stats_reset",
 ]
 
 _lib = None
@@ -132,6 +150,7 @@ class Derp:
         if lib().derp_create(C.byref(h), device, a, self.S, b, self.D):
             raise DerpError(lib().derp_last_error(None).decode())
         self.h = h
+        self._seqs = []  # derp_seq objects living on this context (destroyed first)
         self.sizes = None
         self.opt = Options()
         lib().derp_options_default(C.byref(self.opt))
@@ -139,6 +158,10 @@ class Derp:
 
     def close(self):
         if getattr(self, "h", None):
+            for ref in list(getattr(self, "_seqs", [])):
+                seq = ref()
+                if seq is not None:
+                    seq.close()
             lib().derp_destroy(self.h)
             self.h = None
 
@@ -233,6 +256,18 @@ class Derp:
         self._ck(lib().derp_generate_foreground_mask(self.h, _p(template), _p(frame), w, h, blur_radius,
                                                      C.c_float(threshold), morph_closing_size, _p(out)))
         return out
+
+    # ---- frame slots
+    def set_frame_slots(self, n):
+        self._ck(lib().derp_set_frame_slots(self.h, n))
+
+    def select_frame(self, slot):
+        self._ck(lib().derp_select_frame(self.h, slot))
+
+    def frame_slots(self):
+        n, cur = C.c_int(), C.c_int()
+        self._ck(lib().derp_frame_slots(self.h, C.byref(n), C.byref(cur)))
+        return n.value, cur.value
 
     def upload_frame(self, frame):
         """frame: dict from synth.make_frame (color[level][cam], optional masks / bg_disp)."""

@@ -1,82 +1,350 @@
-"""Frame-parallel sequence schedule: one frame per GPU, one process per GPU.
+"""Frames of a sequence sharded over GPUs: host-side mirror of `derp_seq_*` (include/derp_hip.h).
 
-Reproduces the per-level barrier of the reference's render pipeline
+The schedule is the per-level barrier of the reference's render pipeline
 (scripts/render/pipeline.py:364-408): for level L, coarse to fine,
     DerpCLI(level L) on every frame  ->  TemporalBilateralFilter(level L) over [t-R, t+R]
     ->  "Transfer": the filtered level overwrites disparity_levels/level_L  ->  level L-1.
 The reference moves the +-R frames through the filesystem (TemporalBilateralFilter.cpp:139-160).
-Here the only data that crosses ranks inside the level loop is the raw level-L disparity of the
-+-R neighbour frames, sent point to point (isend / irecv; backend "nccl" = RCCL, where each
-neighbour is one direct xGMI link) — colour guides and masks of the neighbour frames are *inputs*
-and are fetched once before the loop (`neighbour_exchange` on the whole pyramid).
-Compute is injected (HIP library on the GPU box, the oracle in the CPU tests), so the schedule
-itself is testable with gloo.
+Here a rank owns a contiguous chunk of frames (render.py:169-175), and the only data that crosses
+ranks inside the level loop is the raw level-L disparity of the frames a neighbour's window reaches
+into (the halo). Partition, windows and the transfer plan come from the C library's host-only
+functions, so this module, the C++ driver and the tests agree by construction.
+
+`SequenceRunner` drives the HIP library. Transports, tried in this order by `attach_best`:
+  "rccl"      ncclSend/ncclRecv issued by the library itself on its own stream (no torch in the loop)
+  "torch"     the same plan moved with torch.distributed isend/irecv over device-pointer views
+  "broadcast" one torch.distributed broadcast per transferred frame (collective fallback)
+`run_schedule` is the transport-agnostic loop; the CPU tests run it with gloo and the oracle as the
+compute backend.
 """
-import torch
+import ctypes as C
+import weakref
+
+from . import derp
+
+BLOCK, CYCLIC = 0, 1
+KIND_COLOR, KIND_FG, KIND_DISPARITY = 0, 1, 2
 
 
+# ---------------------------------------------------------------- host-only plan (no GPU needed)
 def temporal_window(t, first, last, radius):
     """populateMinMaxFrame (TemporalBilateralFilter.cpp:96-119): frames that exist in
     [t - radius, t + radius], i.e. the window clamped to the sequence [first, last]."""
-    return max(first, t - radius), min(last, t + radius)
+    lo, hi = C.c_int(), C.c_int()
+    derp.lib().derp_seq_window(t, first, last, radius, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
 
 
-def _as_bytes(x):
-    return x if x.dtype in (torch.float32, torch.uint8) else x.view(torch.uint8)
+def owner(first, last, world, frame, partition=BLOCK):
+    return derp.lib().derp_seq_owner(first, last, world, partition, frame)
 
 
-MODE = "p2p"  # "p2p": isend/irecv with the neighbour ranks only; "allgather": one collective, then slice
+def owned_frames(first, last, world, rank, partition=BLOCK):
+    return [t for t in range(first, last + 1) if owner(first, last, world, t, partition) == rank]
 
 
-def neighbour_exchange(x, rank, world, dist=None, radius=2):
-    """Send this rank's tensor to the ranks whose window contains it and receive theirs.
-    -> list of tensors for ranks lo..hi in order (own tensor included, not copied)."""
-    lo, hi = temporal_window(rank, 0, world - 1, radius)
-    if world == 1 or dist is None:
-        return [x]
-    x = x.contiguous()
-    view = _as_bytes(x)
-    if MODE == "allgather":
-        out = torch.empty((world,) + tuple(view.shape), dtype=view.dtype, device=view.device)
-        if dist.get_backend() == "nccl":
-            dist.all_gather_into_tensor(out, view)
-        else:
-            dist.all_gather([out[r] for r in range(world)], view)
-        return [x if r == rank else (out[r].view(x.dtype) if out.dtype != x.dtype else out[r]) for r in range(lo, hi + 1)]
-    recv = {}
-    ops = []
-    for r in range(lo, hi + 1):
-        if r == rank:
+def plan(first, last, world, radius, partition=BLOCK):
+    """-> [(frame, from_rank, to_rank)]: every transfer of one exchange, in the order all ranks post them."""
+    n = derp.lib().derp_seq_plan(first, last, world, radius, partition, None, 0)
+    if n < 0:
+        raise ValueError("bad sequence geometry")
+    buf = (derp.SeqTransfer * max(n, 1))()
+    derp.lib().derp_seq_plan(first, last, world, radius, partition, buf, n)
+    return [(buf[i].frame, buf[i].from_rank, buf[i].to_rank) for i in range(n)]
+
+
+def halo_frames(first, last, world, rank, radius, partition=BLOCK):
+    return sorted({f for (f, a, b) in plan(first, last, world, radius, partition) if b == rank})
+
+
+# ---------------------------------------------------------------- transport-agnostic exchange
+def exchange(transfers, rank, tensor_of, dist, mode="p2p", scratch=None):
+    """Move frames along `transfers`. tensor_of(frame) -> contiguous tensor: the owned frame's buffer on
+    the sender, the halo buffer to fill on the receiver. Returns the bytes this rank received."""
+    received = 0
+    if mode == "p2p":
+        ops = []
+        for (f, a, b) in transfers:
+            if a == rank:
+                ops.append(dist.P2POp(dist.isend, tensor_of(f), b))
+            elif b == rank:
+                t = tensor_of(f)
+                received += t.numel() * t.element_size()
+                ops.append(dist.P2POp(dist.irecv, t, a))
+        if ops:
+            for work in dist.batch_isend_irecv(ops):
+                work.wait()
+        return received
+    # collective fallback: one broadcast per transferred frame; ranks outside the frame's halo take
+    # part with a scratch buffer of the same size (`scratch()`)
+    spare = None
+    done = set()
+    for (f, a, b) in transfers:
+        if f in done:
             continue
-        recv[r] = torch.empty_like(view)
-        ops.append(dist.P2POp(dist.irecv, recv[r], r))
-        ops.append(dist.P2POp(dist.isend, view, r))
-    for work in dist.batch_isend_irecv(ops):
-        work.wait()
-    out = []
-    for r in range(lo, hi + 1):
-        if r == rank:
-            out.append(x)
+        done.add(f)
+        if a == rank or any(bb == rank for (ff, aa, bb) in transfers if ff == f):
+            t = tensor_of(f)
+            if a != rank:
+                received += t.numel() * t.element_size()
         else:
-            out.append(recv[r].view(x.dtype) if recv[r].dtype != x.dtype else recv[r])
-    return out
+            spare = scratch() if spare is None else spare
+            t = spare
+        dist.broadcast(t, src=a)
+    return received
 
 
-def run_level_schedule(rank, world, levels, process_level, disparity_view, static_window, temporal_filter, write_back,
-                       dist=None, time_radius=2):
-    """Drive this rank's frame (frame index = rank) through `levels` (coarse -> fine).
+def run_schedule(backend, levels, first, last, rank, world, radius=2, partition=BLOCK, dist=None, mode="p2p"):
+    """The per-level barrier for this rank's frames with an EXTERNAL transport (torch.distributed).
 
-    process_level(level)                   runs the depth path of this rank's frame at `level`
-    disparity_view(level) -> tensor        this rank's raw level disparity [D, h, w] f32
-    static_window(level) -> (guides, masks) lists over the window's frames (lo..hi), fetched beforehand
-    temporal_filter(level, guides, disps, masks, offset) -> filtered [D, h, w]
-    write_back(level, filtered)            the "Transfer" step
+    backend.compute(level)                 processLevel of every owned frame
+    backend.tensor(frame, level, kind)     buffer of an owned / halo frame (see `exchange`)
+    backend.scratch(level, kind)           same-sized spare buffer (collective fallback only)
+    backend.before_exchange() / after_exchange()   stream fences around foreign-stream traffic
+    backend.filter(level)                  temporal filter of every owned frame + Transfer
     """
-    lo, hi = temporal_window(rank, 0, world - 1, time_radius)
+    transfers = plan(first, last, world, radius, partition) if world > 1 else []
+    received = 0
     for level in levels:
-        process_level(level)
-        disps = neighbour_exchange(disparity_view(level), rank, world, dist, time_radius)
-        guides, masks = static_window(level)
-        filtered = temporal_filter(level, guides, disps, masks, rank - lo)
-        write_back(level, filtered)
-    return lo, hi
+        backend.compute(level)
+        if transfers:
+            backend.before_exchange()
+            received += exchange(transfers, rank, lambda f: backend.tensor(f, level, KIND_DISPARITY), dist, mode,
+                                 lambda: backend.scratch(level, KIND_DISPARITY))
+            backend.after_exchange()
+        backend.filter(level)
+    return received
+
+
+# ---------------------------------------------------------------- HIP-backed runner
+class SequenceRunner:
+    """derp_seq over one `derp.Derp` context: owns the frame slots of this rank's frames."""
+
+    def __init__(self, g, first, last, rank=0, world=1, **options):
+        self.g, self.first, self.last, self.rank, self.world = g, first, last, rank, world
+        self.opt = derp.SeqOptions()
+        derp.lib().derp_seq_options_default(C.byref(self.opt))
+        for k, v in options.items():
+            if not hasattr(self.opt, k):
+                raise KeyError(k)
+            setattr(self.opt, k, type(getattr(self.opt, k))(v))
+        h = C.c_void_p()
+        g._ck(derp.lib().derp_seq_create(C.byref(h), g.h, first, last, rank, world, C.byref(self.opt)))
+        self.h = h
+        g._seqs.append(weakref.ref(self))
+        self.transport = "none" if world > 1 else "local"
+        n_owned, n_halo = C.c_int(), C.c_int()
+        derp.lib().derp_seq_counts(self.h, C.byref(n_owned), C.byref(n_halo))
+        self.owned = self._frames(0, n_owned.value)
+        self.halo = self._frames(1, n_halo.value)
+        self._dist = None
+        self._mode = "p2p"
+        self._stage = False
+        self._pending = []
+
+    def _frames(self, halo, n):
+        buf = (C.c_int * max(n, 1))()
+        derp.lib().derp_seq_frames(self.h, halo, buf, n)
+        return [buf[i] for i in range(n)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            derp.lib().derp_seq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        self.g._ck(rc)
+
+    # ---- inputs
+    def slot(self, frame):
+        return derp.lib().derp_seq_frame_slot(self.h, frame)
+
+    def upload_frame(self, frame, data):
+        """Upload `data` (synth.make_frame dict) as sequence frame `frame` (must be owned)."""
+        s = self.slot(frame)
+        if s < 0:
+            raise ValueError("frame %d is not owned by rank %d" % (frame, self.rank))
+        self.g.select_frame(s)
+        self.g.upload_frame(data)
+
+    def download_disparity(self, frame, level, d):
+        self.g.select_frame(self.slot(frame))
+        return self.g.download_disparity(level, d)
+
+    def buffer(self, frame, level, kind):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(derp.lib().derp_seq_buffer(self.h, frame, level, kind, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def _device_view(self, frame, level, kind):
+        import torch
+
+        p, n = self.buffer(frame, level, kind)
+
+        class _A:
+            pass
+
+        a = _A()
+        a.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (p, False), "version": 3}
+        return torch.as_tensor(a, device=torch.device("cuda", torch.cuda.current_device()))
+
+    def tensor(self, frame, level, kind):
+        """uint8 torch view of an owned / halo frame's device buffer — or, when the backend cannot move
+        device memory (gloo), a host copy to send / a pinned host buffer to receive into, copied to the
+        device buffer by `after_exchange`."""
+        import torch
+
+        dev = self._device_view(frame, level, kind)
+        if not self._stage:
+            return dev
+        if self.slot(frame) >= 0:
+            return dev.cpu()
+        host = torch.empty(dev.shape, dtype=torch.uint8).pin_memory()
+        self._pending.append((dev, host))
+        return host
+
+    def scratch(self, level, kind):
+        import torch
+
+        w, h = self.g.sizes[level]
+        n = w * h * (self.g.S * 8 if kind == KIND_COLOR else self.g.S if kind == KIND_FG else self.g.D * 4)
+        return torch.empty(n, dtype=torch.uint8, device=torch.device("cuda", torch.cuda.current_device()))
+
+    # ---- transports
+    def attach_loopback(self, peers):
+        arr = (C.c_void_p * len(peers))(*[p.h for p in peers])
+        self._ck(derp.lib().derp_seq_attach_loopback(self.h, arr, len(peers)))
+        self.transport = "loopback"
+
+    def attach_rccl(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(derp.lib().derp_seq_attach_rccl(self.h, buf, 128))
+        self.transport = "rccl"
+
+    def attach_torch(self, dist, mode="p2p", stage_on_host=False):
+        self._ck(derp.lib().derp_seq_attach_external(self.h))
+        self._dist, self._mode, self._stage = dist, mode, stage_on_host
+        self.transport = "torch" if mode == "p2p" else "broadcast"
+
+    def selftest(self, words=4096):
+        self._ck(derp.lib().derp_seq_selftest(self.h, words))
+
+    def attach_best(self, dist, prefer=("rccl", "torch", "broadcast"), log=None):
+        """Attach the first transport that every rank can use (agreement via all_reduce MIN)."""
+        import torch
+
+        def agree(ok):
+            t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item() > 0.5)
+
+        for name in prefer:
+            ok, why = True, ""
+            try:
+                if name == "rccl":
+                    ident = [rccl_unique_id() if self.rank == 0 else None]
+                    dist.broadcast_object_list(ident, src=0)
+                    self.attach_rccl(ident[0])
+                    self.selftest()
+                else:
+                    self.attach_torch(dist, "p2p" if name == "torch" else "broadcast")
+                    probe = torch.full((64,), float(self.rank), device="cuda")
+                    got = torch.empty_like(probe)
+                    nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+                    if name == "torch":
+                        for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, probe, nxt),
+                                                         dist.P2POp(dist.irecv, got, prv)]):
+                            w.wait()
+                        torch.cuda.synchronize()
+                        ok = bool((got == float(prv)).all().item())
+            except Exception as e:  # noqa: BLE001
+                ok, why = False, str(e)
+            if agree(ok):
+                return name
+            if log and self.rank == 0:
+                log("sequence: transport %s unavailable (%s)" % (name, why or "a peer failed"))
+        raise RuntimeError("no usable transport between the ranks")
+
+    # ---- schedule
+    def exchange_inputs(self):
+        if self.transport in ("torch", "broadcast"):
+            transfers = plan(self.first, self.last, self.world, self.opt.time_radius, self.opt.partition)
+            self.before_exchange()
+            kinds = [KIND_COLOR] + ([KIND_FG] if self.opt.use_foreground_masks else [])
+            for level in range(len(self.g.sizes)):
+                for kind in kinds:
+                    exchange(transfers, self.rank, lambda f: self.tensor(f, level, kind), self._dist, self._mode,
+                             lambda: self.scratch(level, kind))
+                    self.after_exchange()
+        else:
+            self._ck(derp.lib().derp_seq_exchange_inputs(self.h))
+
+    def compute(self, level):
+        self._ck(derp.lib().derp_seq_level_compute(self.h, level))
+
+    def exchange_level(self, level):
+        self._ck(derp.lib().derp_seq_level_exchange(self.h, level))
+
+    def filter(self, level):
+        self._ck(derp.lib().derp_seq_level_filter(self.h, level))
+
+    def before_exchange(self):
+        self.g.synchronize()  # the level's kernels ran on the library's stream
+
+    def after_exchange(self):
+        import torch
+
+        for dev, host in self._pending:
+            dev.copy_(host)
+        self._pending = []
+        torch.cuda.synchronize()  # received tensors were produced on torch's / RCCL's streams
+
+    def run(self, level_start=None, level_end=0):
+        """All levels, coarse to fine, with whichever transport is attached."""
+        level_start = len(self.g.sizes) - 1 if level_start is None else level_start
+        if self.transport in ("local", "rccl"):
+            self._ck(derp.lib().derp_seq_run(self.h, level_start, level_end))
+        elif self.transport in ("torch", "broadcast"):
+            run_schedule(self, range(level_start, level_end - 1, -1), self.first, self.last, self.rank, self.world,
+                         self.opt.time_radius, self.opt.partition, self._dist, self._mode)
+        else:
+            raise RuntimeError("transport %r needs the phases driven by the caller" % self.transport)
+
+    def stats(self):
+        a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._ck(derp.lib().derp_seq_stats(self.h, C.byref(a), C.byref(b), C.byref(ms)))
+        return dict(bytes_sent=a.value, bytes_received=b.value, exchange_ms=ms.value)
+
+    def stats_reset(self):
+        self._ck(derp.lib().derp_seq_stats_reset(self.h))
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    if derp.lib().derp_rccl_unique_id(buf, 128):
+        raise RuntimeError("ncclGetUniqueId failed (librccl not loadable?)")
+    return bytes(buf.raw)
+
+
+def run_loopback(runners, level_start, level_end=0):
+    """Several ranks emulated in one process on one GPU: phase by phase across all of them."""
+    for r in runners:
+        r.attach_loopback(runners)
+    for r in runners:
+        r.exchange_inputs()
+    for level in range(level_start, level_end - 1, -1):
+        for r in runners:
+            r.compute(level)
+        for r in runners:
+            r.exchange_level(level)
+        for r in runners:
+            r.filter(level)
+    for r in runners:
+        r.g.synchronize()
+

@@ -84,6 +84,16 @@ int derp_set_options(derp_ctx* ctx, const derp_options* o);
 int derp_set_pyramid(derp_ctx* ctx, int num_levels, const int* widths, const int* heights,
                      int width_full, int height_full);
 
+/* ---- frame slots: several frames of one sequence resident on this GPU ------------------------
+ * The reference keeps a sequence's frames on disk and loads one PyramidLevel at a time
+ * (DerpCLI.cpp:220-323 frame loop); here each frame's colour / mask / background / result pyramid can
+ * stay in HBM. derp_set_frame_slots (after derp_set_pyramid) allocates n_slots pyramids; uploads,
+ * derp_process_*, derp_download_* and derp_dev_* act on the slot chosen by derp_select_frame (slot 0
+ * initially). Working buffers and projection tables are shared by all slots. */
+int derp_set_frame_slots(derp_ctx* ctx, int n_slots);
+int derp_select_frame(derp_ctx* ctx, int slot);
+int derp_frame_slots(const derp_ctx* ctx, int* n_slots, int* selected);
+
 /* ---- inputs (loadLevelImages, ImageUtil.h:79-94; DerpCLI.cpp:235-248,276-303) ------------ */
 int derp_upload_color(derp_ctx* ctx, int level, int src, const uint16_t* bgr);
 int derp_upload_foreground_mask(derp_ctx* ctx, int level, int src, const uint8_t* mask);
@@ -205,10 +215,74 @@ int derp_temporal_filter_dev(derp_ctx* ctx, const void* const* guides_bgrx_dev,
                              int n_frames, int w, int h, int frame_offset, float sigma,
                              int space_radius, float weight0, float weight1, float weight2,
                              float* out_dev);
-/* device views of the resident pyramid (for the RCCL neighbour exchange; not owned by caller) */
+/* device views of the selected frame's resident pyramid (not owned by the caller). Pointer lifetime:
+ * derp_dev_disparity / derp_dev_color stay valid until derp_set_pyramid / derp_set_frame_slots /
+ * derp_destroy; their CONTENT is written by kernels on the context's stream, so call derp_synchronize
+ * before reading it from another stream. derp_dev_mask computes fov & fg of every destination at
+ * `level` into a buffer of its own and has finished when it returns; that buffer is reused by the next
+ * derp_dev_mask call (copy it if you need two levels at once). */
 int derp_dev_disparity(derp_ctx* ctx, int level, int dst, float** ptr, size_t* bytes);
 int derp_dev_color(derp_ctx* ctx, int level, int src, void** ptr_bgrx_u16, size_t* bytes);
 int derp_dev_mask(derp_ctx* ctx, int level, int dst, uint8_t** ptr_fov_and_fg, size_t* bytes);
+
+/* ---- sequence driver: frames of a sequence sharded over GPUs ----------------------
+ * Replaces the depth_estimation stage of scripts/render/pipeline.py:364-408 for the frames one process
+ * (= one GPU) owns: per level L, coarse to fine, DerpCLI(L) on every frame -> TemporalBilateralFilter(L)
+ * over the window [t - R, t + R] clamped to the sequence (TemporalBilateralFilter.cpp:96-119) ->
+ * "Transfer" (the filtered level overwrites disparity_levels/level_L) -> level L-1. Frames are
+ * partitioned over `world` ranks in contiguous chunks (render.py:169-175) or cyclically; the raw level
+ * disparity of the frames a neighbour rank's window reaches into is the only data exchanged inside the
+ * level loop. Transports: RCCL send/recv on the context's stream (derp_seq_attach_rccl), same-process
+ * loopback (tests: several ranks emulated on one GPU), or external (the caller moves the buffers that
+ * derp_seq_buffer names). */
+typedef struct derp_seq derp_seq;
+enum { DERP_SEQ_BLOCK = 0, DERP_SEQ_CYCLIC = 1 };
+typedef struct {
+  int32_t time_radius;          /* --time_radius  2     TemporalBilateralFilter.cpp:54 */
+  float sigma;                  /* --sigma        0.01  :51 */
+  float weight_b;               /* --weight_b     0.5   :57 */
+  float weight_g;               /* --weight_g     1.0   :58 */
+  float weight_r;               /* --weight_r     1.0   :59; never read by the reference (:176-178 passes b, g, b) */
+  int32_t space_radius;         /* --space_radius -1 = max(ceil(0.9^level), 1)  :52,164-168 */
+  int32_t use_foreground_masks; /* temporal masking (pipeline.py:386 do_temporal_masking) */
+  int32_t partition;            /* DERP_SEQ_BLOCK | DERP_SEQ_CYCLIC */
+  int32_t do_temporal_filter;   /* 0 = replicas: no window, no exchange (pipeline.py:378) */
+} derp_seq_options;
+typedef struct {
+  int32_t frame, from_rank, to_rank;
+} derp_seq_transfer;
+void derp_seq_options_default(derp_seq_options* o);
+/* host-only plan (no GPU needed): window of a frame, owner of a frame, and every (frame, from, to)
+ * transfer of one exchange, in the global order all ranks post them. derp_seq_plan returns the count. */
+void derp_seq_window(int frame, int first, int last, int time_radius, int* lo, int* hi);
+int derp_seq_owner(int first, int last, int world, int partition, int frame);
+int derp_seq_plan(int first, int last, int world, int time_radius, int partition, derp_seq_transfer* out, int cap);
+/* Allocates one frame slot per owned frame (derp_set_frame_slots) and the halo buffers; call after
+ * derp_set_pyramid and before uploading frames. Upload frame t with derp_select_frame(ctx,
+ * derp_seq_frame_slot(seq, t)) + the derp_upload_* / derp_build_pyramid_* functions. */
+int derp_seq_create(derp_seq** out, derp_ctx* ctx, int first, int last, int rank, int world,
+                    const derp_seq_options* opt);
+void derp_seq_destroy(derp_seq* seq);
+int derp_seq_counts(const derp_seq* seq, int* n_owned, int* n_halo);
+int derp_seq_frames(const derp_seq* seq, int halo, int* frames, int cap);
+int derp_seq_frame_slot(const derp_seq* seq, int frame);   /* -1 when not owned by this rank */
+/* buffer of an owned or halo frame: kind 0 colour [S][h*w] BGRX u16, 1 fg mask [S][h*w] u8,
+ * 2 level disparity [D][h*w] f32 */
+int derp_seq_buffer(derp_seq* seq, int frame, int level, int kind, void** ptr, size_t* bytes);
+/* transports */
+int derp_rccl_unique_id(void* out128, size_t cap);         /* ncclGetUniqueId; rank 0 calls, caller distributes */
+int derp_seq_attach_rccl(derp_seq* seq, const void* unique_id, size_t bytes);
+int derp_seq_attach_loopback(derp_seq* seq, derp_seq* const* peers, int n_peers);
+int derp_seq_attach_external(derp_seq* seq);
+int derp_seq_selftest(derp_seq* seq, int words);           /* one ring step over RCCL, verified */
+/* schedule */
+int derp_seq_exchange_inputs(derp_seq* seq);               /* colour (+ fg) pyramids of the halo frames, once */
+int derp_seq_level_compute(derp_seq* seq, int level);      /* processLevel(level) of every owned frame */
+int derp_seq_level_exchange(derp_seq* seq, int level);     /* raw level disparity of the halo frames */
+int derp_seq_level_filter(derp_seq* seq, int level);       /* temporal filter of every owned frame + Transfer */
+int derp_seq_run(derp_seq* seq, int level_start, int level_end);
+int derp_seq_stats(derp_seq* seq, uint64_t* bytes_sent, uint64_t* bytes_received, double* exchange_ms);
+int derp_seq_stats_reset(derp_seq* seq);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* computeCost evaluations and (evaluation, src) pairs reaching computeSSD since the last reset:

@@ -78,3 +78,105 @@ def bit_equal(a, b):
         return int((a.view(np.uint32) != b.view(np.uint32)).sum() - ((np.isnan(a) & np.isnan(b)).sum()
                    - ((a.view(np.uint32) == b.view(np.uint32)) & np.isnan(a)).sum()))
     return int((a != b).sum())
+
+
+class OracleSequence:
+    """`sequence.run_schedule` backend with the CPU oracle as compute: what a rank holds for its owned
+    frames plus the halo buffers it receives into. Test infrastructure (the product backend is
+    `sequence.SequenceRunner` over the HIP library)."""
+
+    def __init__(self, rig, sizes, res, first, last, rank=0, world=1, radius=2, partition=0, threads=2,
+                 use_foreground_masks=False, **opts):
+        import torch
+
+        from facebook360_dep_amd import sequence, synth
+
+        self.rig, self.sizes, self.res = rig, sizes, res
+        self.first, self.last, self.rank, self.world, self.radius = first, last, rank, world, radius
+        self.threads, self.opts, self.use_fg, self.partition = threads, opts, use_foreground_masks, partition
+        self.n = len(rig["cameras"])
+        self.owned = sequence.owned_frames(first, last, world, rank, partition)
+        self.halo = sequence.halo_frames(first, last, world, rank, radius, partition) if world > 1 else []
+        self.frames = {t: synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu",
+                                           with_masks=use_foreground_masks) for t in self.owned}
+        # [frame][level] tensors; owned colour comes from the rendered frame, halo buffers start empty
+        self.color, self.disp, self.fg = {}, {}, {}
+        for t in self.owned + self.halo:
+            self.color[t], self.disp[t], self.fg[t] = {}, {}, {}
+            for level, (w, h) in enumerate(sizes):
+                if t in self.frames:
+                    self.color[t][level] = torch.from_numpy(np.ascontiguousarray(np.stack(self.frames[t]["color"][level])))
+                    if use_foreground_masks:
+                        self.fg[t][level] = torch.from_numpy(np.ascontiguousarray(np.stack(self.frames[t]["masks"][level])))
+                else:
+                    self.color[t][level] = torch.zeros((self.n, h, w, 3), dtype=torch.uint16)
+                    if use_foreground_masks:
+                        self.fg[t][level] = torch.zeros((self.n, h, w), dtype=torch.uint8)
+                self.disp[t][level] = torch.zeros((self.n, h, w), dtype=torch.float32)
+        self.fov = {}
+        self.raw = {}  # [(frame, level)] unfiltered level result, kept for the tests
+
+    # ---- run_schedule backend
+    def compute(self, level):
+        for t in self.owned:
+            prev = None
+            if level + 1 < len(self.sizes):
+                prev = [self.disp[t][level + 1][d].numpy() for d in range(self.n)]
+            L = oracle_level(self.rig, self.sizes, self.frames[t], level, self.res, self.res, prev,
+                             partial_coverage=True, threads=self.threads, use_foreground_masks=self.use_fg,
+                             **self.opts)
+            L.process()
+            for d in range(self.n):
+                self.disp[t][level][d] = __import__("torch").from_numpy(L.get_dst(d)[0])
+            self.raw[(t, level)] = self.disp[t][level].numpy().copy()
+            if level not in self.fov:
+                self.fov[level] = np.stack([L.fov_mask(d) for d in range(self.n)])
+
+    def tensor(self, frame, level, kind):
+        src = {0: self.color, 1: self.fg, 2: self.disp}[kind][frame][level]
+        return src.view(__import__("torch").uint8).reshape(-1)
+
+    def scratch(self, level, kind):
+        import torch
+
+        return torch.empty_like(self.tensor(self.owned[0] if self.owned else self.halo[0], level, kind))
+
+    def before_exchange(self):
+        pass
+
+    def after_exchange(self):
+        pass
+
+    def filter(self, level):
+        import torch
+
+        from facebook360_dep_amd import sequence
+
+        out = {}
+        for t in self.owned:
+            lo, hi = sequence.temporal_window(t, self.first, self.last, self.radius)
+            res = []
+            for d in range(self.n):
+                masks = []
+                for u in range(lo, hi + 1):
+                    m = self.fov[level][d]
+                    if self.use_fg:
+                        m = m & self.fg[u][level][d].numpy()
+                    masks.append(m)
+                # weights (b, g, b): TemporalBilateralFilter.cpp:176-178
+                res.append(O.temporal_filter([self.color[u][level][d].numpy() for u in range(lo, hi + 1)],
+                                             [self.disp[u][level][d].numpy() for u in range(lo, hi + 1)], masks,
+                                             t - lo, 0.01, O.temporal_space_radius(level), 0.5, 1.0, 0.5,
+                                             threads=self.threads))
+            out[t] = torch.from_numpy(np.stack(res))
+        for t in self.owned:  # "Transfer" after every owned frame is filtered
+            self.disp[t][level].copy_(out[t])
+
+    def exchange_inputs(self, dist, mode="p2p"):
+        from facebook360_dep_amd import sequence
+
+        transfers = sequence.plan(self.first, self.last, self.world, self.radius, self.partition)
+        for level in range(len(self.sizes)):
+            for kind in [0] + ([1] if self.use_fg else []):
+                sequence.exchange(transfers, self.rank, lambda f: self.tensor(f, level, kind), dist, mode,
+                                  lambda: self.scratch(level, kind))

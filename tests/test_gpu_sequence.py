@@ -1,0 +1,301 @@
+"""BASELINE config 3 on the GPU: the per-level barrier schedule (DerpCLI(L) -> temporal filter(L) ->
+Transfer -> L-1; scripts/render/pipeline.py:364-408, TemporalBilateralFilter.cpp:96-184) driven by the
+library's sequence driver (`derp_seq_*`) with HIP compute, compared with the CPU oracle running the same
+schedule — every level of every frame — on one rank, on several ranks emulated on one GPU (loopback
+transport), and on two processes sharing cuda:0 over gloo (external transport). Also: the RCCL transport's
+self-test on a 1-rank communicator, and `derp_dev_*` / `derp_temporal_filter_dev` through device pointers."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from tests import common
+
+pytestmark = pytest.mark.gpu
+
+FIRST, LAST = 0, 4  # 5 frames, radius 2: windows {0,1,2} {0..3} {0..4} {1..4} {2,3,4} — clamped at both ends
+
+
+def _bad(got, want):
+    got, want = np.asarray(got, np.float32), np.asarray(want, np.float32)
+    return int((~((got == want) | (np.isnan(got) & np.isnan(want)))).sum())
+
+
+def _setup(name):
+    from facebook360_dep_amd import synth
+
+    n, res, widths = synth.config(name)
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    return n, res, rig, sizes
+
+
+def _gpu_runner(rig, sizes, res, first, last, rank=0, world=1, **opts):
+    from facebook360_dep_amd import derp, sequence, synth
+
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid(sizes, res, res)
+    r = sequence.SequenceRunner(g, first, last, rank, world, **opts)
+    for t in r.owned:
+        r.upload_frame(t, synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu"))
+    return g, r
+
+
+_oracle = {}
+
+
+def _oracle_sequence(name, first, last):
+    """Single-process oracle run of the schedule (cached per rig): .disp[t][level], .raw[(t, level)]."""
+    from facebook360_dep_amd import sequence
+
+    key = (name, first, last)
+    if key not in _oracle:
+        n, res, rig, sizes = _setup(name)
+        seq = common.OracleSequence(rig, sizes, res, first, last, threads=-1)
+        sequence.run_schedule(seq, list(range(len(sizes) - 1, -1, -1)), first, last, 0, 1)
+        _oracle[key] = seq
+    return _oracle[key]
+
+
+def _compare_with_oracle(runners, ref, n, sizes):
+    """Every level of every frame; the libm caveat of test_gpu_parity applies (glibc vs OCML last ulp)."""
+    worst = 0
+    for r in runners:
+        for t in r.owned:
+            for level in range(len(sizes)):
+                for d in range(n):
+                    got = r.download_disparity(t, level, d)
+                    want = ref.disp[t][level][d].numpy()
+                    bad, _ = common.compare_disparity(got, want, 1e-4)
+                    assert bad == 0, (r.rank, t, level, d, bad)
+                    worst = max(worst, _bad(got, want))
+    return worst
+
+
+def test_sequence_one_rank_against_oracle(built):
+    """5 frames resident on one GPU (frame slots), full pyramid, temporal filter seeded level to level."""
+    n, res, rig, sizes = _setup("tiny")
+    g, r = _gpu_runner(rig, sizes, res, FIRST, LAST)
+    assert r.owned == [0, 1, 2, 3, 4] and r.halo == [] and g.frame_slots()[0] == 5
+    r.run()
+    g.synchronize()
+    ref = _oracle_sequence("tiny", FIRST, LAST)
+    assert _compare_with_oracle([r], ref, n, sizes) == 0  # bit-equal on this rig
+    # the stage did something and the next level really starts from the FILTERED level: an unfiltered
+    # pyramid of frame 2 differs at level 0
+    from facebook360_dep_amd import derp, synth
+
+    solo = derp.Derp(rig["cameras"], partial_coverage=1)
+    solo.set_pyramid(sizes, res, res)
+    solo.upload_frame(synth.make_frame(rig, sizes, frame=2, seed=362, device="cpu"))
+    solo.process_pyramid()
+    assert _bad(solo.download_disparity(0, 0), r.download_disparity(2, 0, 0)) > 0
+    assert _bad(solo.download_disparity(len(sizes) - 1, 0), ref.raw[(2, len(sizes) - 1)][0]) == 0
+    solo.close()
+    st = r.stats()
+    assert st["bytes_sent"] == 0 and st["bytes_received"] == 0
+    g.close()
+
+
+@pytest.mark.parametrize("world,partition", [(2, 0), (3, 0), (3, 1), (5, 0)])
+def test_sequence_ranks_on_one_gpu_loopback(built, world, partition):
+    """`world` ranks emulated on one GPU, each with its own context and frame slots; the halo frames'
+    raw level disparity moves device to device along the plan. Result = the oracle's, for the block and
+    the cyclic partition, including one frame per rank (world 5 = the one-frame-per-GPU shape)."""
+    from facebook360_dep_amd import sequence
+
+    n, res, rig, sizes = _setup("tiny")
+    made = [_gpu_runner(rig, sizes, res, FIRST, LAST, rank, world, partition=partition) for rank in range(world)]
+    runners = [r for (_, r) in made]
+    assert sorted(t for r in runners for t in r.owned) == list(range(FIRST, LAST + 1))
+    sequence.run_loopback(runners, len(sizes) - 1)
+    ref = _oracle_sequence("tiny", FIRST, LAST)
+    assert _compare_with_oracle(runners, ref, n, sizes) == 0
+    # exactly the planned traffic: colour pyramid once + one disparity level per (transfer, level)
+    plan = sequence.plan(FIRST, LAST, world, 2, partition)
+    px = sum(w * h for (w, h) in sizes)
+    assert sum(r.stats()["bytes_received"] for r in runners) == len(plan) * px * n * (8 + 4)
+    assert sum(r.stats()["bytes_sent"] for r in runners) == len(plan) * px * n * (8 + 4)
+    for (g, r) in made:
+        g.close()
+
+
+def test_sequence_sixteen_cameras_against_oracle(built):
+    """Config 3's rig (16 cameras) at 128^2, 3 frames split over 2 emulated ranks."""
+    from facebook360_dep_amd import sequence, synth
+
+    n, res, widths = 16, 128, [128, 100, 80, 60, 50]
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    first, last = 0, 2
+    ref = common.OracleSequence(rig, sizes, res, first, last, threads=-1)
+    sequence.run_schedule(ref, list(range(len(sizes) - 1, -1, -1)), first, last, 0, 1)
+    made = []
+    for rank in range(2):
+        from facebook360_dep_amd import derp
+
+        g = derp.Derp(rig["cameras"])
+        g.set_pyramid(sizes, res, res)
+        r = sequence.SequenceRunner(g, first, last, rank, 2)
+        for t in r.owned:
+            r.upload_frame(t, synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu"))
+        made.append((g, r))
+    sequence.run_loopback([r for (_, r) in made], len(sizes) - 1)
+    flips = _compare_with_oracle([r for (_, r) in made], ref, n, sizes)
+    print("16-camera sequence: %d float differences vs the oracle" % flips)
+    for (g, r) in made:
+        g.close()
+
+
+def test_sequence_foreground_masks(built):
+    """Temporal masking (pipeline.py:386): mask = fg & fov per window frame; fg masks of halo frames are
+    exchanged with the inputs."""
+    from facebook360_dep_amd import derp, sequence, synth
+
+    n, res, rig, sizes = _setup("tiny")
+    first, last = 0, 2
+    ref = common.OracleSequence(rig, sizes, res, first, last, threads=-1, use_foreground_masks=True)
+    sequence.run_schedule(ref, list(range(len(sizes) - 1, -1, -1)), first, last, 0, 1)
+    made = []
+    for rank in range(2):
+        g = derp.Derp(rig["cameras"], partial_coverage=1, use_foreground_masks=1)
+        g.set_pyramid(sizes, res, res)
+        r = sequence.SequenceRunner(g, first, last, rank, 2, use_foreground_masks=1)
+        for t in r.owned:
+            r.upload_frame(t, synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu", with_masks=True))
+        made.append((g, r))
+    sequence.run_loopback([r for (_, r) in made], len(sizes) - 1)
+    assert _compare_with_oracle([r for (_, r) in made], ref, n, sizes) == 0
+    for (g, r) in made:
+        g.close()
+
+
+def test_sequence_without_temporal_filter_is_replicas(built):
+    """do_temporal_filter = 0: no halo, no exchange, every frame equals a stand-alone pyramid."""
+    from facebook360_dep_amd import derp, synth
+
+    n, res, rig, sizes = _setup("tiny")
+    g, r = _gpu_runner(rig, sizes, res, 0, 1, do_temporal_filter=0)
+    r.run()
+    solo = derp.Derp(rig["cameras"], partial_coverage=1)
+    solo.set_pyramid(sizes, res, res)
+    solo.upload_frame(synth.make_frame(rig, sizes, frame=1, seed=361, device="cpu"))
+    solo.process_pyramid()
+    for d in range(n):
+        assert _bad(r.download_disparity(1, 0, d), solo.download_disparity(0, d)) == 0
+    solo.close()
+    g.close()
+
+
+def test_rccl_transport_selftest_single_rank(built):
+    """librccl is bound at run time; a 1-rank communicator sends to itself on the library's stream."""
+    from facebook360_dep_amd import sequence
+
+    n, res, rig, sizes = _setup("tiny")
+    g, r = _gpu_runner(rig, sizes, res, 0, 1)
+    r.attach_rccl(sequence.rccl_unique_id())
+    r.selftest(1 << 16)
+    r.run()  # world 1 over the RCCL transport object: no transfers, same result path
+    g.synchronize()
+    ref = _oracle_sequence("tiny", 0, 1)
+    assert _compare_with_oracle([r], ref, n, sizes) == 0
+    g.close()
+
+
+def test_frame_slots_and_dev_pointers(built):
+    """derp_select_frame switches which frame uploads / process / derp_dev_* refer to; derp_dev_mask is
+    complete on return and lives in its own buffer; derp_temporal_filter_dev on those device pointers
+    equals the host-pointer entry point."""
+    import torch
+
+    from facebook360_dep_amd import derp, synth
+
+    n, res, rig, sizes = _setup("tiny")
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid(sizes, res, res)
+    g.set_frame_slots(3)
+    frames = [synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu") for t in range(3)]
+    for t in range(3):
+        g.select_frame(t)
+        g.upload_frame(frames[t])
+        g.process_pyramid()
+    g.synchronize()
+    with pytest.raises(derp.DerpError):
+        g.select_frame(3)
+    level = 0
+    w, h = sizes[level]
+    ptrs = {"g": [], "d": [], "m": []}
+    host = {"d": [], "m": None}
+    for t in range(3):
+        g.select_frame(t)
+        ptrs["g"].append(g.dev_color(level, 1)[0])
+        ptrs["d"].append(g.dev_disparity(level, 1)[0])
+        host["d"].append(g.download_disparity(level, 1))
+    assert len(set(ptrs["d"])) == 3 and len(set(ptrs["g"])) == 3  # three distinct resident pyramids
+    mp_, nb = g.dev_mask(level, 1)
+    assert nb == w * h
+
+    class _A:  # read the mask back through torch's view of the pointer
+        __cuda_array_interface__ = {"shape": (h, w), "typestr": "|u1", "data": (mp_, False), "version": 3}
+
+    mask = torch.as_tensor(_A(), device="cuda").cpu().numpy()
+    assert np.array_equal(mask, g.fov_mask(1, w, h))
+    out = torch.empty((h, w), dtype=torch.float32, device="cuda")
+    g.temporal_filter_dev(ptrs["g"], ptrs["d"], [mp_] * 3, w, h, 1, 0.01, 1, 0.5, 1.0, 0.5, out.data_ptr())
+    g.synchronize()
+    want = g.temporal_filter([frames[t]["color"][level][1] for t in range(3)], host["d"], [mask] * 3, 1, 0.01, 1, 0.5,
+                             1.0, 0.5)
+    assert _bad(out.cpu().numpy(), want) == 0
+    # slot 0's result is still frame 0's: equal to a stand-alone run
+    solo = derp.Derp(rig["cameras"], partial_coverage=1)
+    solo.set_pyramid(sizes, res, res)
+    solo.upload_frame(frames[0])
+    solo.process_pyramid()
+    g.select_frame(0)
+    assert _bad(g.download_disparity(0, 2), solo.download_disparity(0, 2)) == 0
+    solo.close()
+    g.close()
+
+
+def _gloo_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from facebook360_dep_amd import sequence
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, res, rig, sizes = _setup("tiny")
+    g, r = _gpu_runner(rig, sizes, res, FIRST, LAST, rank, world)
+    r.attach_torch(dist, "p2p", stage_on_host=True)  # gloo moves host tensors; the GPU path stages through pinned memory
+    r.exchange_inputs()
+    r.run()
+    g.synchronize()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+             **{"f%d_l%d" % (t, lv): np.stack([r.download_disparity(t, lv, d) for d in range(n)])
+                for t in r.owned for lv in range(len(sizes))})
+    g.close()
+    dist.destroy_process_group()
+
+
+def test_sequence_two_processes_one_gpu_gloo(built, tmp_path):
+    """world_size 2, both ranks on cuda:0, HIP compute, the external transport driven by torch.distributed."""
+    import torch.multiprocessing as mp
+
+    from facebook360_dep_amd import sequence
+
+    world = 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_gloo_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    ref = _oracle_sequence("tiny", FIRST, LAST)
+    n, res, rig, sizes = _setup("tiny")
+    for rank in range(world):
+        z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
+        for t in sequence.owned_frames(FIRST, LAST, world, rank):
+            for lv in range(len(sizes)):
+                assert _bad(z["f%d_l%d" % (t, lv)], ref.disp[t][lv].numpy()) == 0, (rank, t, lv)
