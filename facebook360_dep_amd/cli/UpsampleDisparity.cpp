@@ -101,12 +101,20 @@ int main(int argc, char** argv) {
         const int radius = (int)(scale * scale + 1);
         LOG_INFO(fmt("Applying filter with radius %d to %dx%d disparity to %s...", radius, wUp, hUp, rigDst[i].id));
         const std::vector<uint16_t> c16 = load_color_bgr16(image_path(F.s("color"), rigDst[i].id, frame), w2, h2);
-        CHECK_MSG(w2 == wUp && h2 == hUp,
-                  "colour must already be at the output resolution (INTER_AREA colour resize belongs to the pyramid builder)");
+        CHECK_MSG(w2 >= wUp && h2 >= hUp,
+                  "colour guide smaller than the output resolution (the pipeline passes the smallest colour level "
+                  "that is at least as large, pipeline.py:410-411)");
         std::vector<float> guide(c16.size());
         const float s = 1.0f / 65535.0f;  // loadImage<Vec3f>: convertTo(CV_32F, 1/65535)
         for (size_t k = 0; k < c16.size(); ++k) {
           guide[k] = c16[k] * s;
+        }
+        if (w2 != wUp || h2 != hUp) {
+          // colorUp = cv_util::resizeImage(colors[i], sizeUp): INTER_AREA on Vec3f (UpsampleDisparity.cpp:117,
+          // CvUtil.h:139-147)
+          std::vector<float> guideUp((size_t)wUp * hUp * 3);
+          DERP_OK(ctx, derp_resize_area(ctx, 3, guide.data(), w2, h2, guideUp.data(), wUp, hUp));
+          guide.swap(guideUp);
         }
         std::vector<float> filtered(up.size());
         DERP_OK(ctx, derp_joint_bilateral_f32(ctx, up.data(), guide.data(), maskUp.data(), wUp, hUp, radius,

@@ -159,6 +159,10 @@ struct Flags {
         usage();
         exit(0);
       }
+      if (name == "helpxml") {  // gflags' machine-readable flag table (name / meaning / default / type)
+        helpxml();
+        exit(0);
+      }
       auto it = defs.find(name);
       if (it == defs.end() && name.rfind("no", 0) == 0 && defs.count(name.substr(2)) &&
           defs[name.substr(2)].type == "bool") {
@@ -208,7 +212,33 @@ struct Flags {
       printf("    -%s (%s) type: %s default: %s\n", n.c_str(), d.help.c_str(), d.type.c_str(), d.value.c_str());
     }
   }
+  static std::string xml_escape(const std::string& v) {
+    std::string o;
+    for (char ch : v) {
+      o += ch == '&' ? "&amp;" : ch == '<' ? "&lt;" : ch == '>' ? "&gt;" : std::string(1, ch);
+    }
+    return o;
+  }
+  std::map<std::string, std::string> declared;  // defaults as declared, before any command-line value
+  std::string program;
+  void helpxml() const {
+    printf("<?xml version=\"1.0\"?>\n<AllFlags>\n<program>%s</program>\n<usage>%s</usage>\n", program.c_str(),
+           xml_escape(usage_msg).c_str());
+    for (const auto& n : order) {
+      const Def& d = defs.at(n);
+      const auto it = declared.find(n);
+      printf("<flag><file>%s</file><name>%s</name><meaning>%s</meaning><default>%s</default><current>%s</current>"
+             "<type>%s</type></flag>\n",
+             program.c_str(), n.c_str(), xml_escape(d.help).c_str(),
+             xml_escape(it == declared.end() ? d.value : it->second).c_str(), xml_escape(d.value).c_str(), d.type.c_str());
+    }
+    printf("</AllFlags>\n");
+  }
   void parse(int argc, char** argv) {
+    program = std::filesystem::path(argv[0]).filename().string();
+    for (const auto& n : order) {
+      declared[n] = defs.at(n).value;
+    }
     // glog flags the pipeline passes (res/flags/*.flags); logging always goes to stderr as well
     str("log_dir", "", "glog: directory for <program>.INFO");
     boolean("alsologtostderr", false, "glog: accepted");

@@ -325,8 +325,10 @@ int get_lanczos(derp_ctx* c, int ssize, int dsize, LanczosTab** out) {
 
 // cv::resize INTER_AREA, one axis: resize.cpp computeResizeAreaTab (fractional scales) or the integer
 // scale factor of the "area fast" paths (|scale - round(scale)| < DBL_EPSILON)
-int get_area_tab(derp_ctx* c, int ssize, int dsize, AreaTabDev** out) {
-  auto key = std::make_pair(ssize, dsize);
+int get_area_tab(derp_ctx* c, int ssize, int dsize, AreaTabDev** out, bool forceTable = false) {
+  // cv::resize takes the integer-factor paths only when BOTH axes have integer factors; otherwise both
+  // axes go through computeResizeAreaTab — forceTable builds the table of an integer-factor axis
+  auto key = std::make_pair(forceTable ? -ssize : ssize, dsize);
   auto it = c->areaTabs.find(key);
   if (it != c->areaTabs.end()) {
     *out = it->second;
@@ -337,7 +339,7 @@ int get_area_tab(derp_ctx* c, int ssize, int dsize, AreaTabDev** out) {
   const int iscale = (int)std::nearbyint(scale);
   std::vector<int> start(dsize + 1, 0), si;
   std::vector<float> alpha;
-  if (iscale >= 1 && std::abs(scale - iscale) < 2.220446049250313e-16) {
+  if (!forceTable && iscale >= 1 && std::abs(scale - iscale) < 2.220446049250313e-16) {
     t->iscale = iscale;
   } else {
     for (int dx = 0; dx < dsize; ++dx) {
@@ -385,17 +387,22 @@ int resize_area_dev(derp_ctx* c, int kind, const void* src, int sw, int sh, void
   AreaTabDev *tx, *ty;
   TRY(get_area_tab(c, sw, dw, &tx));
   TRY(get_area_tab(c, sh, dh, &ty));
+  if ((tx->iscale > 0) != (ty->iscale > 0)) {
+    if (tx->iscale > 0) {
+      TRY(get_area_tab(c, sw, dw, &tx, true));
+    } else {
+      TRY(get_area_tab(c, sh, dh, &ty, true));
+    }
+  }
   AreaAxis ax{tx->start.as<int>(), tx->si.as<int>(), tx->alpha.as<float>(), tx->iscale};
   AreaAxis ay{ty->start.as<int>(), ty->si.as<int>(), ty->alpha.as<float>(), ty->iscale};
-  if ((ax.iscale > 0) != (ay.iscale > 0)) {
-    // cv::resize takes the table path unless BOTH scales are integers; build the missing table
-    return fail(c, "mixed integer / fractional area scales (%dx%d -> %dx%d) are not supported", sw, sh, dw, dh);
-  }
   const dim3 g = grid2d(dw, dh, 1, kBlk2d);
   if (kind == 0) {
     hipLaunchKernelGGL(k_resize_area<0>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
   } else if (kind == 1) {
     hipLaunchKernelGGL(k_resize_area<1>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
+  } else if (kind == 3) {
+    hipLaunchKernelGGL(k_resize_area<3>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
   } else {
     hipLaunchKernelGGL(k_resize_area<2>, g, kBlk2d, 0, c->stream, src, sw, sh, dst, dw, dh, ax, ay, threshold);
   }
@@ -777,6 +784,10 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   int DB = (int)std::min<size_t>((size_t)c->D, budget / std::max<size_t>(per, 1));
   if (DB < 1) {
     return fail(c, "projection tables for one destination (%zu bytes) exceed the table budget (%zu bytes)", per, budget);
+  }
+  {  // equal-sized batches: 24 destinations under a 23-destination budget run as 12 + 12, not 23 + 1
+    const int batches = (c->D + DB - 1) / DB;
+    DB = (c->D + batches - 1) / batches;
   }
   c->DB = DB;
   const size_t wp = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW), cp = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC);
@@ -1487,13 +1498,13 @@ int derp_download_level_background(derp_ctx* c, int level, int dst, float* disp)
   HIPCHK(c, hipMemcpy(disp, c->pyrBg[level].as<float>() + (size_t)dst * n, n * 4, hipMemcpyDeviceToHost));
   return 0;
 }
-// one image: kind 0 = BGR u16 x3, 1 = u8, 2 = f32 (host in / host out)
+// one image: kind 0 = BGR u16 x3, 1 = u8, 2 = f32, 3 = BGR f32 x3 (host in / host out)
 int derp_resize_area(derp_ctx* c, int kind, const void* src, int w, int h, void* dst, int dw, int dh) {
-  if (!c || !src || !dst || kind < 0 || kind > 2 || w <= 0 || h <= 0 || dw <= 0 || dh <= 0) {
+  if (!c || !src || !dst || kind < 0 || kind > 3 || w <= 0 || h <= 0 || dw <= 0 || dh <= 0) {
     return fail(c, "bad arguments");
   }
   HIPCHK(c, hipSetDevice(c->device));
-  const size_t elem = kind == 0 ? 6 : kind == 1 ? 1 : 4, n = (size_t)w * h, nd = (size_t)dw * dh;
+  const size_t elem = kind == 0 ? 6 : kind == 1 ? 1 : kind == 3 ? 12 : 4, n = (size_t)w * h, nd = (size_t)dw * dh;
   DevBuf in, out, out3;
   int rc = 0;
   if (in.ensure(n * elem) || out.ensure(nd * (kind == 0 ? 8 : elem)) || (kind == 0 && out3.ensure(nd * 6))) {

@@ -1565,6 +1565,8 @@ __global__ void k_spiral_fill(const float* __restrict__ dispUp, const float* __r
 //   KIND 0: BGR u16 interleaved in -> BGRX ushort4 out (the pyramid's colour layout)
 //   KIND 1: u8 in -> u8 {0,1} out = (resized > threshold)        (fg masks: threshold 127)
 //   KIND 2: f32 in -> f32 out                                     (background disparity)
+//   KIND 3: f32 x3 interleaved in -> f32 x3 interleaved out        (UpsampleDisparity's Vec3f colour guide,
+//           cv_util::resizeImage CvUtil.h:139-147; channels are independent in cv::resize)
 // ----------------------------------------------------------------------------------------
 struct AreaAxis {
   const int* start;    // [dsize + 1] first table entry of each output index
@@ -1579,6 +1581,8 @@ __device__ __forceinline__ float area_src(const void* src, size_t pix, int c) {
     return (float)reinterpret_cast<const uint16_t*>(src)[pix * 3 + c];
   } else if (KIND == 1) {
     return (float)reinterpret_cast<const uint8_t*>(src)[pix];
+  } else if (KIND == 3) {
+    return reinterpret_cast<const float*>(src)[pix * 3 + c];
   } else {
     return reinterpret_cast<const float*>(src)[pix];
   }
@@ -1591,14 +1595,14 @@ __global__ void k_resize_area(const void* __restrict__ src, int SW, int SH, void
   if (dx >= DW || dy >= DH) {
     return;
   }
-  constexpr int CN = KIND == 0 ? 3 : 1;
+  constexpr int CN = (KIND == 0 || KIND == 3) ? 3 : 1;
   float res[CN];
   if (SW == DW && SH == DH) {
     for (int c = 0; c < CN; ++c) {
       res[c] = area_src<KIND>(src, (size_t)dy * SW + dx, c);
     }
   } else if (ax.iscale > 0 && ay.iscale > 0) {
-    if (ax.iscale == 2 && ay.iscale == 2 && KIND != 2) {
+    if (ax.iscale == 2 && ay.iscale == 2 && KIND != 2 && KIND != 3) {
       for (int c = 0; c < CN; ++c) {
         const size_t p = (size_t)(2 * dy) * SW + 2 * dx;
         const int v = (int)area_src<KIND>(src, p, c) + (int)area_src<KIND>(src, p + 1, c) +
@@ -1649,6 +1653,11 @@ __global__ void k_resize_area(const void* __restrict__ src, int SW, int SH, void
   } else if (KIND == 1) {
     const int v = min(max(cv_round(res[0]), 0), 255);
     reinterpret_cast<uint8_t*>(dst)[o] = threshold >= 0 ? (uint8_t)(v > threshold) : (uint8_t)v;
+  } else if (KIND == 3) {
+    float* q = reinterpret_cast<float*>(dst) + o * 3;
+    for (int c = 0; c < CN; ++c) {
+      q[c] = res[c];
+    }
   } else {
     reinterpret_cast<float*>(dst)[o] = res[0];
   }

@@ -243,8 +243,9 @@ class Derp:
 
     def resize_area(self, src, dw, dh):
         src = np.ascontiguousarray(src)
-        kind = {(np.dtype(np.uint16), 3): 0, (np.dtype(np.uint8), 2): 1, (np.dtype(np.float32), 2): 2}[(src.dtype, src.ndim)]
-        out = np.zeros((dh, dw, 3) if kind == 0 else (dh, dw), dtype=src.dtype)
+        kind = {(np.dtype(np.uint16), 3): 0, (np.dtype(np.uint8), 2): 1, (np.dtype(np.float32), 2): 2,
+                (np.dtype(np.float32), 3): 3}[(src.dtype, src.ndim)]
+        out = np.zeros((dh, dw, 3) if kind in (0, 3) else (dh, dw), dtype=src.dtype)
         self._ck(lib().derp_resize_area(self.h, kind, _p(src), src.shape[1], src.shape[0], _p(out), dw, dh))
         return out
 

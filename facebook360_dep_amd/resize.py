@@ -27,6 +27,17 @@ def get_frame_path(src_dir, camera, frame):
     return os.path.join(cam_dir, frame + ext)
 
 
+def level_sizes(rig_width, rig_height):
+    """(width, height) of every pyramid level for a rig resolution — resize.py:71-74."""
+    ratio = rig_height / rig_width
+    out = []
+    for width in WIDTHS:
+        height = round(ratio * width)
+        height += height % 2
+        out.append((width, height))
+    return out
+
+
 def resize_camera(g, src_dir, dst_dir, camera, rig_resolution, frame, threshold):
     """resize.py:51-85. `g` is a derp.Derp context (any rig: only derp_resize_area is used)."""
     original_file = get_frame_path(src_dir, camera, frame)
@@ -37,10 +48,7 @@ def resize_camera(g, src_dir, dst_dir, camera, rig_resolution, frame, threshold)
     img = imageio.read_pfm(original_file) if ext == ".pfm" else imageio.read_png(original_file)
     if img.ndim == 3 and img.shape[2] == 4:
         img = img[..., :3]
-    ratio = rig_resolution[1] / rig_resolution[0]
-    for level, width in enumerate(WIDTHS):
-        height = round(ratio * width)
-        height += height % 2
+    for level, (width, height) in enumerate(level_sizes(rig_resolution[0], rig_resolution[1])):
         new_file = os.path.join(dst_dir, f"level_{level}", camera, frame_fn)
         os.makedirs(os.path.dirname(new_file), exist_ok=True)
         if width > img.shape[1] or height > img.shape[0]:

@@ -113,7 +113,8 @@ int derp_build_pyramid_background_disparity(derp_ctx* ctx, int dst, const float*
 int derp_download_level_color(derp_ctx* ctx, int level, int src, uint16_t* bgr);
 int derp_download_level_mask(derp_ctx* ctx, int level, int src, uint8_t* mask01);
 int derp_download_level_background(derp_ctx* ctx, int level, int dst, float* disp);
-/* one image: kind 0 = BGR u16 x3, 1 = u8 x1, 2 = f32 x1 */
+/* one image: kind 0 = BGR u16 x3, 1 = u8 x1, 2 = f32 x1, 3 = BGR f32 x3 (cv_util::resizeImage<Vec3f>,
+ * CvUtil.h:139-147 — the colour guide of UpsampleDisparity.cpp:117). Shrinking only. */
 int derp_resize_area(derp_ctx* ctx, int kind, const void* src, int w, int h, void* dst, int dw, int dh);
 
 /* background_subtraction::generateForegroundMask<Vec3w, Vec3f> for one camera

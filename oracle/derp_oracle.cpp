@@ -1798,6 +1798,10 @@ void oracle_cv_resize_area_u8(const uint8_t* src, int sw, int sh, int dw, int dh
 void oracle_cv_resize_area_f32(const float* src, int sw, int sh, int dw, int dh, float* out) {
   resizeAreaCv<float, 1>(src, sw, sh, out, dw, dh);
 }
+// cv_util::resizeImage<cv::Vec3f> (CvUtil.h:139-147): the colour guide of UpsampleDisparity.cpp:117
+void oracle_cv_resize_area_f32c3(const float* src, int sw, int sh, int dw, int dh, float* out) {
+  resizeAreaCv<float, 3>(src, sw, sh, out, dw, dh);
+}
 // libstdc++ behaviours the random-proposal stage depends on (Derp.cpp:757-758,806-808)
 void oracle_minstd_uniform(int seed, int n, float a, float b, float* out) {
   std::default_random_engine engine;

@@ -481,7 +481,7 @@ def cv_resize_nearest(src, dw, dh):
 
 
 def cv_resize_area(src, dw, dh):
-    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) for u16 x3, u8 x1 and f32 x1 images."""
+    """cv2.resize(src, (dw, dh), interpolation=cv2.INTER_AREA) for u16 x3, u8 x1, f32 x1 and f32 x3 images."""
     src = np.ascontiguousarray(src)
     h, w = src.shape[:2]
     if src.dtype == np.uint16 and src.ndim == 3:
@@ -493,6 +493,9 @@ def cv_resize_area(src, dw, dh):
     elif src.dtype == np.float32 and src.ndim == 2:
         out = np.zeros((dh, dw), dtype=np.float32)
         lib().oracle_cv_resize_area_f32(_p(src), w, h, dw, dh, _p(out))
+    elif src.dtype == np.float32 and src.ndim == 3:  # cv::Vec3f (UpsampleDisparity's colour guide)
+        out = np.zeros((dh, dw, 3), dtype=np.float32)
+        lib().oracle_cv_resize_area_f32c3(_p(src), w, h, dw, dh, _p(out))
     else:
         raise TypeError((src.dtype, src.shape))
     return out

@@ -62,6 +62,13 @@ def test_derp_cli_layout_and_values(dataset, tmp_path):
     pfm = dio.read_pfm(os.path.join(out, "disparity_levels", "level_0", ids[0], "000000.pfm"))
     exp = np.clip(np.rint(np.nan_to_num(pfm.astype(np.float32) * np.float32(65535.0), nan=0.0)), 0, 65535)
     assert png.dtype == np.uint16 and np.abs(png.astype(np.int64) - exp.astype(np.int64)).max() <= 1
+    # the PFM container exactly as writeCvMat32FC1ToPFM lays it out (CvUtil.cpp:39-49; pinned by
+    # tests/golden/ref_pfm.json): header literals, then the rows top first
+    raw = open(os.path.join(out, "disparity_levels", "level_0", ids[0], "000000.pfm"), "rb").read()
+    w0, h0 = dataset["sizes"][0]
+    header = ("Pf\n%d %d\n-1.0\n" % (w0, h0)).encode()
+    assert raw.startswith(header) and len(raw) == len(header) + 4 * w0 * h0
+    assert np.array_equal(np.frombuffer(raw[len(header):], dtype="<f4").reshape(h0, w0), pfm, equal_nan=True)
 
 
 def test_derp_cli_resume_and_camera_subset(dataset, tmp_path):
@@ -180,6 +187,31 @@ def test_upsample_cli(dataset, tmp_path):
         got = dio.read_pfm(os.path.join(up_b, cam, "000000.pfm"))
         assert common.compare_disparity(got, ref, 1e-5)[0] == 0, cam
         assert os.path.exists(os.path.join(up_b, cam, "000000.png"))
+    # (c), (d) the colour guide arrives LARGER than the output, as the pipeline passes it (pipeline.py:409-443:
+    # "the smallest colour level larger than our last level"), and is resized with INTER_AREA on Vec3f
+    # (UpsampleDisparity.cpp:117, CvUtil.h:139-147): fractional scale 96 -> 64 and integer scale 96 -> 48
+    lvl2 = os.path.join(out, "disparity_levels", "level_2")
+    for (w_out, h_out) in (dataset["sizes"][1], dataset["sizes"][2]):
+        up_c = str(tmp_path / ("up_c%d" % w_out))
+        run("UpsampleDisparity", "--rig=" + rigf, "--disparity=" + lvl2, "--output=" + up_c,
+            "--resolution=%d" % w_out, "--color=" + color0)
+        for d, cam in enumerate(ids):
+            disp = dio.read_pfm(os.path.join(lvl2, cam, "000000.pfm"))
+            guide = O.cv_resize_area(fr["color"][0][d].astype(np.float32) * np.float32(1.0 / 65535.0), w_out, h_out)
+            assert guide.shape == (h_out, w_out, 3)
+            radius = O.upsample_radius(disp.shape[1], w_out)
+            if disp.shape[1] == w_out:
+                ref = np.where(np.isnan(disp), np.float32(1e-4), disp)  # cv::resize to the same size
+            else:
+                ref = O.upsample_disparity(rd, d, disp, w_out, h_out)
+            ref = O.joint_bilateral_f32(ref, guide, np.ones((h_out, w_out), np.uint8), radius, 0.05, 0.5, 0.5, 1.0)
+            got = dio.read_pfm(os.path.join(up_c, cam, "000000.pfm"))
+            assert common.compare_disparity(got, ref, 1e-5)[0] == 0, (w_out, cam)
+    # a guide smaller than the output is refused loudly
+    p = run("UpsampleDisparity", "--rig=" + rigf, "--disparity=" + lvl2, "--output=" + str(tmp_path / "up_e"),
+            "--resolution=%d" % w_up, "--color=" + os.path.join(root, "video", "color_levels", "level_1"),
+            expect_ok=False)
+    assert p.returncode != 0 and "colour guide smaller" in p.stderr
 
 
 def test_layer_disparities_cli(dataset, tmp_path):
