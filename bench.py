@@ -1,16 +1,21 @@
 #!/usr/bin/env python
-"""bench.py — depth Mpix/s per GPU, full pyramid (BASELINE.json metric).
+"""bench.py — depth Mpix/s (full pyramid, 16-camera 2048^2 rig): BASELINE.json's metric.
 
-A step = one coarse-to-fine pass of the depth path over one synthetic frame whose colour pyramid
-is already resident in HBM: projection tables, colour reprojection, brute force, random proposals,
-ping-pong, bilateral, median, FOV mask and the between-level upsample, for every destination camera
-and every pyramid level. N = 1 runs BASELINE config 2 (16 cameras, 2048^2, single frame); N > 1
-runs config 3's shape: frame r on GPU r (weak scaling), with the per-level temporal joint-bilateral
-filter whose +-2-frame disparity window is exchanged over RCCL (send/recv to the neighbour ranks, xGMI).
+Workload (the same for every --gpus N, so 1/2/4/8 is ONE scaling curve — strong scaling): BASELINE
+config 3, an 8-frame sequence of the 16-camera 2048^2 synthetic rig with the per-level temporal filter
+(scripts/render/pipeline.py:364-408). A step = the whole sequence, coarse to fine: for every level, every
+frame's processLevel (projection tables rebuilt per frame, colour reprojection, brute force, random
+proposals, ping-pong, bilateral, median, FOV mask, upsample hand-off), the exchange of the halo frames' raw
+level disparity between ranks, the temporal filter and the write-back. Frames are sharded over the ranks in
+contiguous chunks (8/N frames per GPU); the exchange is RCCL send/recv issued by the library on its own
+stream (fallbacks: torch.distributed point-to-point, then broadcast). Inputs are resident in HBM when the
+timed region starts.
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task statement), extended with
-`roofline` (dominant kernel = level-0 ping-pong) and `cpu_baseline` (the CPU oracle timed on a
-bounded sample on rank 0 at N = 1).
+At N = 1 the same run also times BASELINE config 2 (one frame, no temporal filter) and reports it as
+`config2_single_frame`, next to `roofline` (dominant kernel = level-0 ping-pong; the kernel is bound by
+VALU issue, not HBM — see DESIGN.md §6) and `cpu_baseline` (the CPU oracle on the host cores).
+
+Prints ONE JSON line on rank 0 (driver contract in the task statement).
 """
 import argparse
 import json
@@ -21,7 +26,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32, 2.4 GHz peak engine clock; HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0
+N_SIMD = 256 * 4
+PEAK_CLOCK_GHZ = 2.4
+VALU_PEAK_GCYC = N_SIMD * PEAK_CLOCK_GHZ  # SIMD-cycles available per second (x 1e9)
 
 
 def parse():
@@ -29,16 +38,18 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", help="cfg1 | cfg2 | cfg4 | small | tiny (default: BASELINE config 2)")
+    ap.add_argument("--config", default="cfg2", help="rig: cfg1 | cfg2 | cfg4 | small | tiny (default: BASELINE config 2/3's rig)")
+    ap.add_argument("--frames", type=int, default=8, help="frames of the sequence (BASELINE config 3: 8)")
+    ap.add_argument("--temporal", type=int, default=1, help="0 = no temporal filter (frames are then independent replicas)")
+    ap.add_argument("--partition", default="block", choices=["block", "cyclic"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="auto")
-    ap.add_argument("--temporal", type=int, default=-1, help="-1: on iff gpus > 1")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the config-2 single-frame leg at N = 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--exchange", default="p2p", choices=["p2p", "allgather"],
-                    help="how the +-2 neighbours' level disparity moves between ranks")
+    ap.add_argument("--exchange", default="rccl,torch,broadcast",
+                    help="transports to try for the halo exchange, in order")
     ap.add_argument("--cache-warp-tables", type=int, default=0,
-                    help="1 = keep the rig-only projection warps across steps (default 0: rebuilt every step, as the "
-                         "reference does per frame)")
+                    help="1 = keep the rig-only projection warps across frames (default 0: rebuilt for every frame "
+                         "and level, as the reference does)")
     return ap.parse_args()
 
 
@@ -47,31 +58,58 @@ def b_alg(n_cost, n_pair):
     return 64.0 * n_cost + 272.0 * n_pair
 
 
-def cpu_baseline(cams_n, widths_from, sample):
-    """The CPU oracle ("port") on a bounded sample of the same workload: the same rig, the pyramid
-    truncated to start at `sample` px wide. Returns (Mpix/s of that sample, cores, description)."""
+def cpu_baseline(rig, sizes, frame, res, n_cams):
+    """the CPU oracle ("port") on this host's cores. Config 1 in full; config 2's own frame
+    with levels 9..2 measured and levels 1-0 extrapolated from level 2's time per pixel (the full-size
+    levels would take minutes). Returns the cpu_baseline object."""
     import numpy as np  # noqa: F401
 
     from facebook360_dep_amd import synth
     from tests import common
 
-    rig = synth.make_rig(cams_n, sample)
-    widths = [w for w in widths_from if w <= sample]
-    sizes = synth.level_sizes(sample, sample, widths)
-    frame = synth.make_frame(rig, sizes)
     cores = os.cpu_count() or 1
+    out = {"unit": "Mpix/s", "cores": cores, "kind": "port"}
+    # --- config 1 in full (4 x 512^2, 8 levels)
+    n1, r1, w1 = synth.config("cfg1")
+    rig1 = synth.make_rig(n1, r1)
+    sizes1 = synth.level_sizes(r1, r1, w1)
+    frame1 = synth.make_frame(rig1, sizes1)
     t0 = time.time()
-    cnt = {}
-    common.oracle_pyramid(rig, sizes, frame, sample, sample, counters=cnt, partial_coverage=True, threads=-1)
-    dt = time.time() - t0
-    mpix = cams_n * sample * sample / dt / 1e6
-    return mpix, cores, "%d-camera %dx%d rig, full %d-level pyramid, %.1f s on %d threads" % (
-        cams_n, sample, sample, len(sizes), dt, cores), cnt
+    common.oracle_pyramid(rig1, sizes1, frame1, r1, r1, partial_coverage=True, threads=-1)
+    t1 = time.time() - t0
+    out["config1_full"] = {"value": round(n1 * r1 * r1 / t1 / 1e6, 4), "seconds": round(t1, 2),
+                           "workload": "BASELINE config 1 in full: 4 x 512^2, %d levels" % len(sizes1)}
+    # --- the bench rig: coarse levels measured, the finest extrapolated
+    first_measured = next((lv for lv, (w, h) in enumerate(sizes) if w <= 512), len(sizes) - 1)
+    t_levels = {}
+    prev = None
+    for level in range(len(sizes) - 1, first_measured - 1, -1):
+        t0 = time.time()
+        L = common.oracle_level(rig, sizes, frame, level, res, res, prev, partial_coverage=int(n_cams <= 4), threads=-1)
+        L.process()
+        prev = [L.get_dst(d)[0] for d in range(L.D)]
+        t_levels[level] = time.time() - t0
+    measured = sum(t_levels.values())
+    w, h = sizes[first_measured]
+    per_px = t_levels[first_measured] / (w * h)
+    extra = sum(per_px * sizes[lv][0] * sizes[lv][1] for lv in range(first_measured))
+    total = measured + extra
+    w0, h0 = sizes[0]
+    out["value"] = round(n_cams * w0 * h0 / total / 1e6, 4)
+    out["sample"] = ("frame 0 of the bench workload (%d cameras, %dx%d): levels %d..%d measured in %.1f s on %d threads; "
+                     "levels %d..0 EXTRAPOLATED from level %d's time per pixel (+%.1f s) -> %.1f s per frame. "
+                     "Not the timed workload itself: one frame, no temporal filter."
+                     % (n_cams, w0, h0, len(sizes) - 1, first_measured, measured, cores, first_measured - 1,
+                        first_measured, extra, total)) if first_measured > 0 else (
+        "frame 0 of the bench workload in full: %.1f s on %d threads" % (measured, cores))
+    out["extrapolated"] = first_measured > 0
+    out["measured_seconds"] = round(measured, 2)
+    return out
 
 
 def main():
     args = parse()
-    import numpy as np
+    import numpy as np  # noqa: F401
     import torch
 
     from facebook360_dep_amd import derp, sequence, synth
@@ -93,97 +131,39 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-    temporal = (world > 1) if args.temporal < 0 else bool(args.temporal)
+    temporal = bool(args.temporal)
 
     n_cams, res, widths = synth.config(args.config)
     rig = synth.make_rig(n_cams, res)
     sizes = synth.level_sizes(res, res, widths)
-    frame_index = rank  # frame t -> GPU t (one frame per GPU)
-    frame = synth.make_frame(rig, sizes, frame=frame_index, seed=360 + frame_index, device="cuda")
+    n_levels = len(sizes)
+    first, last = 0, args.frames - 1
+    partition = sequence.BLOCK if args.partition == "block" else sequence.CYCLIC
 
     g = derp.Derp(rig["cameras"], device=local_rank, partial_coverage=int(n_cams <= 4),
                   rebuild_warp_tables=int(not args.cache_warp_tables))
     g.set_pyramid(sizes, res, res)
-    t0 = time.time()
-    g.upload_frame(frame)
-    upload_s = time.time() - t0
-    upload_bytes = sum(w * h for (w, h) in sizes) * n_cams * 6
-    n_levels = len(sizes)
+    runner = sequence.SequenceRunner(g, first, last, rank, world, do_temporal_filter=int(temporal), partition=partition)
+    upload_s, frame0 = 0.0, None
+    for t in runner.owned:  # every rank renders and uploads only the frames it owns
+        frame = synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cuda")
+        t0 = time.time()
+        runner.upload_frame(t, frame)
+        upload_s += time.time() - t0
+        if t == 0:
+            frame0 = frame
+    upload_bytes = sum(w * h for (w, h) in sizes) * n_cams * 6 * len(runner.owned)
 
-    # ---- temporal stage (config 3). Inputs of the +-2 neighbour frames (colour guides, fov & fg masks)
-    # are fetched ONCE here, before the timed loop — they are inputs, like the rank's own colour pyramid.
-    # Inside the loop only the raw level disparity crosses ranks, point to point (RCCL send/recv over the
-    # direct xGMI links), window clamped to the sequence (populateMinMaxFrame, TemporalBilateralFilter.cpp:96-119).
-    def wrap(ptr, nbytes, dtype, shape):
-        class _A:
-            pass
-
-        a = _A()
-        a.__cuda_array_interface__ = {"shape": shape, "typestr": np.dtype(dtype).str, "data": (ptr, False),
-                                      "version": 3}
-        return torch.as_tensor(a, device=torch.device("cuda", local_rank))
-
-    views, static, tbuf = {}, {}, {}
-    exchange_bytes = 0
-    sequence.MODE = args.exchange
-    if temporal and world > 1 and sequence.MODE == "p2p":
-        # probe the point-to-point path once; every rank must agree on the mode, so fall back together
-        ok = torch.ones(1, device="cuda")
-        try:
-            sequence.neighbour_exchange(torch.zeros(16, device="cuda"), rank, world, dist)
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            ok.zero_()
-            if rank == 0:
-                print("bench: p2p exchange unavailable (%s); using all_gather" % e, file=sys.stderr)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if ok.item() == 0:
-            sequence.MODE = "allgather"
-    if temporal:
-        for level in range(n_levels):
-            w, h = sizes[level]
-            p, nb = g.dev_disparity(level, 0)
-            views[level] = wrap(p, nb * n_cams, np.float32, (n_cams, h, w))
-            p, nb = g.dev_color(level, 0)
-            col = wrap(p, nb * n_cams, np.uint16, (n_cams, h, w, 4))
-            p, nb = g.dev_mask(level, 0)
-            msk = wrap(p, nb * n_cams, np.uint8, (n_cams, h, w)).clone()  # dev_mask reuses a working buffer
-            g.synchronize()
-            static[level] = (sequence.neighbour_exchange(col, rank, world, dist),
-                             sequence.neighbour_exchange(msk, rank, world, dist))
-            tbuf[level] = torch.empty((n_cams, h, w), dtype=torch.float32, device=col.device)
-            lo, hi = sequence.temporal_window(rank, 0, world - 1, 2)
-            exchange_bytes += (hi - lo) * n_cams * w * h * 4
-        torch.cuda.synchronize()
-
-    def disparity_view(level):
-        g.synchronize()  # the level's kernels ran on the library's stream
-        return views[level]
-
-    def temporal_filter(level, guides, disps, masks, offset):
-        w, h = sizes[level]
-        out = tbuf[level]
-        torch.cuda.synchronize()  # received tensors were produced on torch's / RCCL's streams
-        radius = 1  # max(ceil(1 * 0.9^level), 1), TemporalBilateralFilter.cpp:165-168
-        for d in range(n_cams):
-            # sigma 0.01; weights (b, g, b) = (0.5, 1.0, 0.5) — TemporalBilateralFilter.cpp:55,176-178
-            g.temporal_filter_dev([x[d].data_ptr() for x in guides], [x[d].data_ptr() for x in disps],
-                                  [x[d].data_ptr() for x in masks], w, h, offset, 0.01, radius, 0.5, 1.0, 0.5,
-                                  out[d].data_ptr())
+    transport = "local"
+    if world > 1 and temporal:
+        transport = runner.attach_best(dist, prefer=tuple(args.exchange.split(",")),
+                                       log=lambda m: print("bench: " + m, file=sys.stderr))
+        runner.exchange_inputs()  # colour guides of the halo frames: inputs, fetched once, outside the timed region
         g.synchronize()
-        return out
-
-    def write_back(level, filtered):
-        # "Transfer": the filtered level overwrites disparity_levels/level_L (pipeline.py:397-408)
-        views[level].copy_(filtered)
         torch.cuda.synchronize()
 
     def step():
-        if temporal:
-            sequence.run_level_schedule(rank, world, list(range(n_levels - 1, -1, -1)), g.process_level,
-                                        disparity_view, lambda lv: static[lv], temporal_filter, write_back, dist=dist)
-        else:
-            g.process_pyramid()
+        runner.run()
 
     def fence():
         g.synchronize()
@@ -197,6 +177,7 @@ def main():
     fence()
     g.profile_reset()
     g.profile_enable(True)
+    runner.stats_reset()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -210,28 +191,76 @@ def main():
     g.profile_enable(False)
 
     w0, h0 = sizes[0]
-    total_mpix = world * args.steps * n_cams * w0 * h0 / 1e6
+    total_mpix = args.frames * args.steps * n_cams * w0 * h0 / 1e6  # every frame of the sequence, all ranks
     value = total_mpix / dt
 
-    # ---- roofline of the dominant kernel: level-0 ping-pong (one launch per step)
+    # ---- per-rank measurements of the timed region
     pp = g.profile_query("ping_pong", 0)
     launches = max(pp["launches"], 1)
     kernel_ms = pp["ms"] / launches
-    alg_bytes = b_alg(pp["n_cost"], pp["n_pair"]) / launches
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            with open(tpath) as f:
-                tj = json.load(f)
-            traffic = tj.get(args.config, {}).get("ping_pong_level0_bytes_per_launch")
-        except Exception:
-            traffic = None
+    memo = g.profile_memoised("ping_pong", 0) / launches
     stage_ms = {s: round(g.profile_query(s)["ms"] / args.steps, 3) for s in derp.STAGES}
     cnt = g.counters()
-    whole_alg = b_alg(cnt["n_cost"], cnt["n_pair"]) / args.steps
+    xs = runner.stats()
+    exch = {"bytes_received_per_step": xs["bytes_received"] // max(args.steps, 1),
+            "bytes_sent_per_step": xs["bytes_sent"] // max(args.steps, 1),
+            "ms_per_step_on_stream": round(xs["exchange_ms"] / max(args.steps, 1), 3)}
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, exch)
+        exch = {"per_rank": gathered,
+                "bytes_received_per_step": sum(e["bytes_received_per_step"] for e in gathered)}
 
+    # ---- roofline of the dominant kernel: level-0 ping-pong (one launch per frame per step)
+    prof = {}
+    ppath = os.path.join(ROOT, "profiles", "valu_roofline.json")
+    if os.path.exists(ppath):
+        try:
+            with open(ppath) as f:
+                prof = json.load(f).get(args.config, {})
+        except Exception:  # noqa: BLE001
+            prof = {}
+    n_cost_launch = pp["n_cost"] / launches
+    n_pair_launch = pp["n_pair"] / launches
+    # executed = logical minus the evaluations served from the memo (their pairs are not executed either)
+    exec_frac = 1.0 - memo / n_cost_launch if n_cost_launch else 1.0
+    alg_bytes_exec = b_alg(n_cost_launch, n_pair_launch) * exec_frac
+    kernel_s = kernel_ms * 1e-3
+    valu_cycles = prof.get("ping_pong_level0_valu_busy_cycles_per_launch")  # SQ_ACTIVE_INST_VALU x 4 (quad-cycles)
+    achieved = valu_cycles / kernel_s / 1e9 if valu_cycles and kernel_s > 0 else None
+    traffic = prof.get("ping_pong_level0_hbm_bytes_per_launch")
+    roofline = {
+        "kernel": "k_ping_pong @ level 0",
+        "bound": "valu",
+        "achieved": round(achieved, 1) if achieved else None,
+        "peak": VALU_PEAK_GCYC,
+        "unit": "G VALU-busy SIMD-cycles/s",
+        "frac": round(achieved / VALU_PEAK_GCYC, 4) if achieved else None,
+        "traffic": traffic,
+        "kernel_ms": round(kernel_ms, 3),
+        "launches_timed": pp["launches"],
+        "note": ("achieved = SQ_ACTIVE_INST_VALU of one level-0 launch (rocprofv3 --pmc on this bench, "
+                 "profiles/valu_roofline.json; quad-cycles x 4) / this run's HIP-event launch duration; peak = "
+                 "%d SIMDs x %.1f GHz. The kernel gathers from L1/L2-resident tables: HBM is not its bound "
+                 "(hbm_frac below), VALU issue is." % (N_SIMD, PEAK_CLOCK_GHZ)),
+        "valu_busy_frac_at_measured_clock": prof.get("ping_pong_level0_valu_busy_frac"),
+        "profiled_effective_clock_ghz": prof.get("ping_pong_level0_effective_clock_ghz"),
+        "wave_issue_breakdown": prof.get("ping_pong_level0_wave_cycle_shares"),
+        "hbm_traffic_GBps": round(traffic / kernel_s / 1e9, 1) if traffic and kernel_s > 0 else None,
+        "hbm_frac": round(traffic / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_s > 0 else None,
+        "algorithmic": {  # SURVEY 8(d)'s logical gather bytes: secondary, on EXECUTED evaluations only
+            "bytes_per_launch_executed": alg_bytes_exec,
+            "GBps": round(alg_bytes_exec / kernel_s / 1e9, 1) if kernel_s > 0 else None,
+            "frac_of_hbm_peak": round(alg_bytes_exec / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if kernel_s > 0 else None,
+            "note": "logical gathers (64 B / cost call + 272 B / (call, source) pair); neighbouring pixels share "
+                    "texels and L1/L2 serve them, so this can exceed the HBM peak and is not a bound",
+            "n_cost_per_launch": n_cost_launch, "n_pair_per_launch": n_pair_launch,
+            "memoised_cost_evals_per_launch": memo,
+        },
+        "whole_step_algorithmic_GBps": round(b_alg(cnt["n_cost"], cnt["n_pair"]) / dt / 1e9, 1),
+    }
+
+    frames_here = len(runner.owned)
     out = {
         "metric": "depth Mpix/s per GPU (full pyramid, 16-cam 2048^2 rig); % HBM-read roofline",
         "value": round(value, 3),
@@ -241,65 +270,54 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32+f64",  # photometry in f32 over u16 texels; camera geometry in f64
         "data": "synthetic",
         "config": {
-            "workload": ("%s: %d-camera %dx%d synthetic rig, single frame, full %d-level pyramid"
-                         % ({"cfg1": "BASELINE config 1", "cfg2": "BASELINE config 2", "cfg4": "BASELINE config 4"}.get(
-                             args.config, "developer config " + args.config), n_cams, res, res, n_levels))
-                        if not temporal else
-                        ("BASELINE config 3 shape: %d-camera %dx%d rig, %d-frame sequence one frame per GPU, "
-                         "per-level temporal filter with RCCL send/recv of the +-2 neighbours' level disparity" %
-                         (n_cams, res, res, world)),
+            "workload": ("BASELINE config 3: %d-camera %dx%d synthetic rig, %d-frame sequence, full %d-level pyramid per "
+                         "frame, %s; the same sequence for every --gpus N (%s partition, %d frame(s) on this rank)"
+                         % (n_cams, res, res, args.frames, n_levels,
+                            "per-level temporal filter (+-2 frames)" if temporal else "no temporal filter",
+                            args.partition, frames_here)),
             "name": args.config,
             "cameras": n_cams,
             "resolution": [res, res],
             "levels": [list(s) for s in sizes],
-            "frames_per_step": world,
+            "frames": args.frames,
             "temporal_filter": temporal,
-            "neighbour_exchange_bytes_received_per_step": exchange_bytes,
-            "neighbour_exchange": sequence.MODE if temporal and world > 1 else None,
-            "warp_tables": "cached" if args.cache_warp_tables else "rebuilt every step",
+            "halo_transport": transport,
+            "halo_exchange": exch,
+            "warp_tables": "cached" if args.cache_warp_tables else "rebuilt for every frame and level",
             "parallelism": "frames x%d" % world,
         },
         "per_gpu_value": round(value / world, 3),
-        "roofline": {
-            "kernel": "k_ping_pong @ level 0",
-            "bound": "hbm",
-            "achieved": round(achieved, 1),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic,
-            "traffic_GBps": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic and kernel_ms > 0 else None),
-            "note": ("achieved / frac price the ALGORITHMIC bytes of SURVEY 8(d) (64 B per cost call + 272 B per "
-                     "(call, source) pair as the reference issues them); neighbouring pixels share texels, so "
-                     "L1/L2 serve most of them and frac can pass 1.0 — traffic is what crossed HBM "
-                     "(rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/hbm_traffic.json)"),
-            "kernel_ms": round(kernel_ms, 3),
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "n_cost_per_launch": pp["n_cost"] / launches,
-            "n_pair_per_launch": pp["n_pair"] / launches,
-            "memoised_cost_evals_per_launch": g.profile_memoised("ping_pong", 0) / launches,
-            "whole_step_algorithmic_GBps": round(whole_alg / (dt / args.steps) / 1e9, 1),
-            "whole_step_frac_of_peak": round(whole_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-        },
+        "ms_per_frame": round(dt / args.steps / args.frames * 1e3 * world, 3),
+        "roofline": roofline,
         "stage_ms_per_step": stage_ms,
         "input_upload": {"bytes": upload_bytes, "seconds": round(upload_s, 3),
-                         "note": "host->HBM staging of the colour pyramid, outside the timed region"},
+                         "note": "host->HBM staging of this rank's colour pyramids, outside the timed region"},
         "device": g.device_name(),
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # bounded sample sized for roughly 10-30 s of oracle time on this host's cores
-        cores_here = os.cpu_count() or 1
-        sample = min(res, 512 if cores_here >= 128 else 256 if cores_here >= 32 else 128)
-        if args.cpu_sample != "auto":
-            sample = int(args.cpu_sample)
-        mpix, cores, desc, _ = cpu_baseline(n_cams, widths, sample)
-        out["cpu_baseline"] = {"value": round(mpix, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
-                               "sample": desc}
+
+    if world == 1 and not args.no_single_frame:
+        # BASELINE config 2: one frame (slot 0), no temporal filter — DerpCLI's own level loop
+        g.select_frame(0)
+        g.process_pyramid()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            g.process_pyramid()
+        fence()
+        d2 = time.perf_counter() - t0
+        out["config2_single_frame"] = {
+            "value": round(args.steps * n_cams * w0 * h0 / 1e6 / d2, 3), "unit": "Mpix/s",
+            "ms_per_frame": round(d2 / args.steps * 1e3, 3),
+            "workload": "BASELINE config 2: %d-camera %dx%d rig, single frame, full %d-level pyramid, no temporal filter"
+                        % (n_cams, res, res, n_levels)}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and frame0 is not None:
+        out["cpu_baseline"] = cpu_baseline(rig, sizes, frame0, res, n_cams)
+    runner.close()
     g.close()
     if rank == 0:
         print(json.dumps(out))

@@ -691,7 +691,7 @@ int derp_seq_run(derp_seq* q, int level_start, int level_end_) {
   if (level_start < level_end_) {
     return fail(c, "Check failed: level_start >= level_end (%d vs %d)", level_start, level_end_);
   }
-  if (q->world > 1 && q->transport != SEQ_RCCL) {
+  if (!q->plan.empty() && q->transport != SEQ_RCCL) {
     return fail(c, "derp_seq_run drives all three phases itself and needs the RCCL transport; with loopback / "
                    "external transports call derp_seq_level_compute / _exchange / _filter per level");
   }

@@ -132,7 +132,9 @@ class SequenceRunner:
         g._ck(derp.lib().derp_seq_create(C.byref(h), g.h, first, last, rank, world, C.byref(self.opt)))
         self.h = h
         g._seqs.append(weakref.ref(self))
-        self.transport = "none" if world > 1 else "local"
+        has_transfers = world > 1 and bool(plan(first, last, world, self.opt.time_radius, self.opt.partition)) \
+            and bool(self.opt.do_temporal_filter)
+        self.transport = "none" if has_transfers else "local"  # nothing to move: replicas
         n_owned, n_halo = C.c_int(), C.c_int()
         derp.lib().derp_seq_counts(self.h, C.byref(n_owned), C.byref(n_halo))
         self.owned = self._frames(0, n_owned.value)

@@ -50,6 +50,7 @@ def test_derp_cli_layout_and_values(dataset, tmp_path):
             d = os.path.join(out, "disparity_levels", "level_%d" % level, cam)
             assert sorted(os.listdir(d)) == ["000000.pfm", "000000.png", "000001.pfm", "000001.png"]
     assert sorted(os.listdir(os.path.join(out, "disparity"))) == sorted(ids)  # createLevelOutputDirs
+    total_bad = 0
     for f in (0, 1):
         ref = common.oracle_pyramid(dataset["rig"], dataset["sizes"], dataset["frames"][f], dataset["res"],
                                     dataset["res"], partial_coverage=True)
@@ -58,6 +59,8 @@ def test_derp_cli_layout_and_values(dataset, tmp_path):
                 got = dio.read_pfm(os.path.join(out, "disparity_levels", "level_%d" % level, cam, "%06d.pfm" % f))
                 bad, rel = common.compare_disparity(got, ref[level][d], 1e-4)
                 assert bad <= 1, (f, level, cam, bad, rel)
+                total_bad += bad
+    common.observed("derp_cli.tiny.pixels_outside_1e-4", total_bad)
     png = dio.read_png(os.path.join(out, "disparity_levels", "level_0", ids[0], "000000.png"))
     pfm = dio.read_pfm(os.path.join(out, "disparity_levels", "level_0", ids[0], "000000.pfm"))
     exp = np.clip(np.rint(np.nan_to_num(pfm.astype(np.float32) * np.float32(65535.0), nan=0.0)), 0, 65535)

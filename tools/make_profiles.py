@@ -1,19 +1,25 @@
 #!/usr/bin/env python
 """Turn the files tools/profile_round.sh left in gpurun_out/ into the committed profiles/ set:
-trimmed kernel stats (derp:: kernels + one aggregate line for the synthetic-input generator),
-per-kernel PMC summaries, the bench lines, and profiles/hbm_traffic.json (read by bench.py).
-FETCH_SIZE is doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half the bytes; confirmed here on
-k_ping_pong_commit, whose reads are 3 x 4 B per pixel); WRITE_SIZE is taken as is (matches the known
-9 B/px of the same kernel). Counters are in KB."""
+trimmed kernel stats (derp:: kernels + one aggregate line for the synthetic-input generator), per-kernel PMC
+summaries (HBM bytes AND the SQ issue counters), the bench lines, and profiles/valu_roofline.json, which
+bench.py reads for `roofline`.
+
+Counter handling, per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE is doubled (gfx950 reports half the
+bytes; confirmed here on k_ping_pong_commit, whose reads are 3 x 4 B per pixel), WRITE_SIZE is taken as is;
+both are in KB. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x 4 = cycles);
+GRBM_GUI_ACTIVE counts cycles. "level-0 launch" = the dispatch with the largest value of each counter
+(the finest level is by far the biggest launch of a kernel).
+usage: tools/make_profiles.py <tag> <config>"""
 import csv
 import json
 import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 src, dst = "gpurun_out", "profiles"
+N_SIMD = 1024
 rows = list(csv.reader(open(os.path.join(src, tag + "_kernel_stats_full.csv"))))
 hdr, body = rows[0], rows[1:]
 keep = [r for r in body if "derp::" in r[0]]  # templates print as "void derp::k<...>(...)"
@@ -23,40 +29,82 @@ with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
     w.writerow(hdr)
     for r in keep:
         w.writerow(r)
-    w.writerow(["(non-derp kernels: torch synthetic-input rendering / copies, outside the timed region)",
+    w.writerow(["(non-derp kernels: torch synthetic-input rendering / copies / RCCL, outside the depth path)",
                 sum(int(r[1]) for r in other), sum(int(r[2]) for r in other), "", "", "", "", ""])
 pm = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    d = json.load(open(os.path.join(src, "%s_pmc_%s.json" % (tag, c))))
+for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ISSUE", "SQ_INSTS"):
+    path = os.path.join(src, "%s_pmc_%s.json" % (tag, c))
+    if not os.path.exists(path):
+        continue
+    d = json.load(open(path))
     d = {k: v for k, v in d.items() if "derp::" in k}
     json.dump(d, open(os.path.join(dst, "%s_pmc_%s.json" % (tag, c)), "w"), indent=1, sort_keys=True)
     pm[c] = d
 for f in ("_bench.json", "_bench_under_rocprof.json"):
-    shutil.copy(os.path.join(src, tag + f), os.path.join(dst, tag + f))
+    if os.path.exists(os.path.join(src, tag + f)):
+        shutil.copy(os.path.join(src, tag + f), os.path.join(dst, tag + f))
 
 
-def kb(counter, kernel, field):
-    for k, v in pm[counter].items():
-        if kernel in k:
+def val(group, kernel, counter, field):
+    for k, v in pm.get(group, {}).items():
+        if kernel in k and counter in v:
             return v[counter][field]
     return 0.0
 
 
-tr = {}
-path = os.path.join(dst, "hbm_traffic.json")
-if os.path.exists(path):
-    tr = json.load(open(path))
-fetch = 2.0 * 1024.0 * kb("FETCH_SIZE", "k_ping_pong(", "max")
-write = 1024.0 * kb("WRITE_SIZE", "k_ping_pong(", "max")
-tr[cfg] = {
-    "source": "%s_pmc_FETCH_SIZE.json / %s_pmc_WRITE_SIZE.json (rocprofv3 --pmc, separate passes)" % (tag, tag),
-    "ping_pong_level0_fetch_bytes": fetch,
-    "ping_pong_level0_write_bytes": write,
-    "ping_pong_level0_bytes_per_launch": fetch + write,
-    "corrections": "FETCH_SIZE KB x2 (gfx950 half-count), WRITE_SIZE KB x1",
-    "all_levels_fetch_bytes": {n: 2.0 * 1024.0 * kb("FETCH_SIZE", n, "sum") for n in
-                               ("k_ping_pong(", "k_random_proposals", "k_reproject", "k_proj_warp", "k_joint_bilateral",
-                                "k_blur3_u16", "k_masked_median", "k_brute_costs")},
+def kernel_view(kernel):
+    fetch = 2.0 * 1024.0 * val("FETCH_SIZE", kernel, "FETCH_SIZE", "max")
+    write = 1024.0 * val("WRITE_SIZE", kernel, "WRITE_SIZE", "max")
+    g = lambda c: val("SQ_ISSUE", kernel, c, "max")  # noqa: E731
+    wave, valu, gui = g("SQ_WAVE_CYCLES"), g("SQ_ACTIVE_INST_VALU"), g("GRBM_GUI_ACTIVE")
+    out = {"hbm_fetch_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
+           "hbm_bytes_per_launch": fetch + write}
+    if wave:
+        out["valu_busy_cycles_per_launch"] = 4.0 * valu
+        out["wave_cycle_shares"] = {
+            "valu": round(valu / wave, 4), "scalar": round(g("SQ_ACTIVE_INST_SCA") / wave, 4),
+            "lds": round(g("SQ_ACTIVE_INST_LDS") / wave, 4), "wait_any": round(g("SQ_WAIT_ANY") / wave, 4),
+            "wait_inst_any": round(g("SQ_WAIT_INST_ANY") / wave, 4)}
+        if gui:
+            # GRBM_GUI_ACTIVE: cycles the launch kept the GPU busy; 1024 SIMDs can each issue VALU every cycle
+            out["valu_busy_frac"] = round(4.0 * valu / (N_SIMD * gui), 4)
+            out["waves_per_simd_avg"] = round(4.0 * wave / (N_SIMD * gui), 3)
+            out["gui_active_cycles_per_launch"] = gui
+    i = lambda c: val("SQ_INSTS", kernel, c, "max")  # noqa: E731
+    if i("SQ_INSTS_VALU"):
+        out["insts_per_launch"] = {"valu": i("SQ_INSTS_VALU"), "salu": i("SQ_INSTS_SALU"), "lds": i("SQ_INSTS_LDS"),
+                                   "vmem_rd": i("SQ_INSTS_VMEM_RD")}
+        out["lds_bank_conflict_over_idx_active"] = round(i("SQ_LDS_BANK_CONFLICT") / max(i("SQ_LDS_IDX_ACTIVE"), 1.0), 4)
+        out["valu_lane_utilisation"] = round(i("SQ_THREAD_CYCLES_VALU") / max(64.0 * val("SQ_ISSUE", kernel, "SQ_ACTIVE_INST_VALU", "max"), 1.0), 4)
+    return out
+
+
+path = os.path.join(dst, "valu_roofline.json")
+tr = json.load(open(path)) if os.path.exists(path) else {}
+pp = kernel_view("k_ping_pong(")
+entry = {
+    "source": "%s_pmc_{FETCH_SIZE,WRITE_SIZE,SQ_ISSUE,SQ_INSTS}.json (rocprofv3 --pmc, one pass per group, on "
+              "`bench.py --steps 1 --warmup 0`); %s_kernel_stats.csv for durations" % (tag, tag),
+    "corrections": "FETCH_SIZE KB x2 (gfx950 half-count), WRITE_SIZE KB x1; SQ quad-cycles x4",
+    "ping_pong_level0_valu_busy_cycles_per_launch": pp.get("valu_busy_cycles_per_launch"),
+    "ping_pong_level0_valu_busy_frac": pp.get("valu_busy_frac"),
+    "ping_pong_level0_wave_cycle_shares": pp.get("wave_cycle_shares"),
+    "ping_pong_level0_hbm_bytes_per_launch": pp.get("hbm_bytes_per_launch"),
+    "kernels_level0_launch": {n: kernel_view(n) for n in
+                              ("k_ping_pong(", "k_random_proposals", "k_reproject", "k_blur3_u16", "k_joint_bilateral",
+                               "k_temporal", "k_proj_warp", "k_brute_costs")},
+    "all_launches_fetch_bytes": {n: 2.0 * 1024.0 * val("FETCH_SIZE", n, "FETCH_SIZE", "sum") for n in
+                                 ("k_ping_pong(", "k_random_proposals", "k_reproject", "k_proj_warp",
+                                  "k_joint_bilateral", "k_blur3_u16", "k_masked_median", "k_brute_costs", "k_temporal")},
 }
+# effective clock of the profiled level-0 launch: GRBM cycles / its duration in the kernel trace (max duration row)
+for r in keep:
+    if "k_ping_pong(" in r[0] and pp.get("gui_active_cycles_per_launch"):
+        try:
+            max_ns = float(r[hdr.index("MaxNs")])
+            entry["ping_pong_level0_trace_max_ms"] = max_ns / 1e6
+        except (ValueError, IndexError):
+            pass
+tr[cfg] = entry
 json.dump(tr, open(path, "w"), indent=1, sort_keys=True)
-print(json.dumps(tr[cfg], indent=1))
+print(json.dumps({k: v for k, v in entry.items() if k.startswith("ping_pong")}, indent=1))
