@@ -35,11 +35,13 @@ enum Stage {
   ST_BILATERAL,
   ST_MEDIAN,
   ST_MASKFOV,
+  ST_TEMPORAL,
   ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"fov_mask",  "variance",    "own_bias",         "upsample",  "proj_warp",
                                      "reproject", "proj_bias",   "brute_force",      "random_proposals",
-                                     "ping_pong", "mismatches",  "bilateral",        "median",    "mask_fov"};
+                                     "ping_pong", "mismatches",  "bilateral",        "median",    "mask_fov",
+                                     "temporal"};
 constexpr int kMaxLevels = 24;
 
 struct DevBuf {

@@ -638,6 +638,7 @@ int derp_seq_level_filter(derp_seq* q, int level) {
   }
   const int W = c->LW[level], H = c->LH[level];
   const size_t n = (size_t)W * H;
+  Span sp(c, ST_TEMPORAL, level);  // masks + temporal kernels + write-back of every owned frame
   hipLaunchKernelGGL(k_fov_mask, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), W, H,
                      q->fov.as<uint8_t>());
   KCHECK(c);

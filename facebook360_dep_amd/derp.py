@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("DERP_LIB") or os.path.join(_HERE, "libderp_hip.so")
 CAM_TYPES = {"FTHETA": 0, "RECTILINEAR": 1, "EQUISOLID": 2, "ORTHOGRAPHIC": 3}
 
 STAGES = ["fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject", "proj_bias", "brute_force",
-          "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov"]
+          "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov", "temporal"]
 
 
 class SeqOptions(C.Structure):

@@ -292,7 +292,8 @@ int derp_get_counters(derp_ctx* ctx, uint64_t* n_cost, uint64_t* n_pair, uint64_
 int derp_reset_counters(derp_ctx* ctx);
 /* per-stage HIP-event timing on the context's own stream, plus per-stage computeCost counters.
  * stage names: "fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject",
- * "proj_bias", "brute_force", "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov".
+ * "proj_bias", "brute_force", "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov", "temporal" (the
+ * sequence driver's filter + Transfer).
  * level = -1 aggregates all levels. ms / launches / n_cost / n_pair may be NULL. */
 int derp_profile_enable(derp_ctx* ctx, int on);
 int derp_profile_reset(derp_ctx* ctx);

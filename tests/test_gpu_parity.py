@@ -564,7 +564,8 @@ def test_config4_full_size_properties(built, monkeypatch):
         interior = sum(int(g.fov_mask(d, w, h)[1:-1, 1:-1].sum()) for d in range(n))
         pp = g.profile_query("ping_pong", level)["n_cost"]
         rp = g.profile_query("random_proposals", level)["n_cost"]
-        assert pp <= 9 * interior and pp >= 0.9 * 9 * interior
+        # at 4096^2 the same scene is sampled twice as finely: more pixels fall under the variance gate
+        assert pp <= 9 * interior and pp >= 0.8 * 9 * interior
         assert rp <= 3 * interior and rp % 3 == 0
     g.close()
 

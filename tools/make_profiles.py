@@ -6,8 +6,9 @@ bench.py reads for `roofline`.
 
 Counter handling, per /opt/skills/guides/MI355X_MICROARCH.md: FETCH_SIZE is doubled (gfx950 reports half the
 bytes; confirmed here on k_ping_pong_commit, whose reads are 3 x 4 B per pixel), WRITE_SIZE is taken as is;
-both are in KB. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x 4 = cycles);
-GRBM_GUI_ACTIVE counts cycles. "level-0 launch" = the dispatch with the largest value of each counter
+both are in KB. SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x 4 = cycles), summed over the
+chip. GRBM_GUI_ACTIVE counts cycles and is summed over the 8 XCDs (checked: value / 8 / launch duration =
+2.3-2.4 GHz), so the chip-busy cycles of a launch are GRBM_GUI_ACTIVE / 8. "level-0 launch" = the dispatch with the largest value of each counter
 (the finest level is by far the biggest launch of a kernel).
 usage: tools/make_profiles.py <tag> <config>"""
 import csv
@@ -20,6 +21,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 src, dst = "gpurun_out", "profiles"
 N_SIMD = 1024
+N_XCD = 8
 rows = list(csv.reader(open(os.path.join(src, tag + "_kernel_stats_full.csv"))))
 hdr, body = rows[0], rows[1:]
 keep = [r for r in body if "derp::" in r[0]]  # templates print as "void derp::k<...>(...)"
@@ -66,10 +68,12 @@ def kernel_view(kernel):
             "lds": round(g("SQ_ACTIVE_INST_LDS") / wave, 4), "wait_any": round(g("SQ_WAIT_ANY") / wave, 4),
             "wait_inst_any": round(g("SQ_WAIT_INST_ANY") / wave, 4)}
         if gui:
-            # GRBM_GUI_ACTIVE: cycles the launch kept the GPU busy; 1024 SIMDs can each issue VALU every cycle
-            out["valu_busy_frac"] = round(4.0 * valu / (N_SIMD * gui), 4)
-            out["waves_per_simd_avg"] = round(4.0 * wave / (N_SIMD * gui), 3)
-            out["gui_active_cycles_per_launch"] = gui
+            # cycles the launch kept the chip busy; each of the 1024 SIMDs could have a VALU instruction active in
+            # every one of them
+            busy = gui / N_XCD
+            out["valu_busy_frac"] = round(4.0 * valu / (N_SIMD * busy), 4)
+            out["waves_per_simd_avg"] = round(4.0 * wave / (N_SIMD * busy), 3)
+            out["chip_busy_cycles_per_launch"] = busy
     i = lambda c: val("SQ_INSTS", kernel, c, "max")  # noqa: E731
     if i("SQ_INSTS_VALU"):
         out["insts_per_launch"] = {"valu": i("SQ_INSTS_VALU"), "salu": i("SQ_INSTS_SALU"), "lds": i("SQ_INSTS_LDS"),
@@ -99,7 +103,7 @@ entry = {
 }
 # effective clock of the profiled level-0 launch: GRBM cycles / its duration in the kernel trace (max duration row)
 for r in keep:
-    if "k_ping_pong(" in r[0] and pp.get("gui_active_cycles_per_launch"):
+    if "k_ping_pong(" in r[0] and pp.get("chip_busy_cycles_per_launch"):
         try:
             max_ns = float(r[hdr.index("MaxNs")])
             entry["ping_pong_level0_trace_max_ms"] = max_ns / 1e6
