@@ -8,6 +8,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -612,27 +617,56 @@ inline Png read_png(const fs::path& path) {
   img.px.resize((size_t)img.w * img.h * img.channels);
   for (int y = 0; y < img.h; ++y) {
     const unsigned char* line = raw.data() + (stride + 1) * y;
-    const int ft = line[0];
-    for (size_t i = 0; i < stride; ++i) {
-      const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-      int pred = 0;
-      switch (ft) {
-        case 0: pred = 0; break;
-        case 1: pred = a; break;
-        case 2: pred = b; break;
-        case 3: pred = (a + b) >> 1; break;
-        case 4: {
-          const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          break;
+    const unsigned char* in = line + 1;
+    const size_t B = (size_t)bpp;
+    switch (line[0]) {  // one tight loop per PNG filter type
+      case 0:
+        memcpy(cur.data(), in, stride);
+        break;
+      case 1:
+        for (size_t i = 0; i < B && i < stride; ++i) {
+          cur[i] = in[i];
         }
-        default: LOG_FATAL("bad PNG filter: " + path.string());
-      }
-      cur[i] = (unsigned char)(line[1 + i] + pred);
+        for (size_t i = B; i < stride; ++i) {
+          cur[i] = (unsigned char)(in[i] + cur[i - B]);
+        }
+        break;
+      case 2:
+        for (size_t i = 0; i < stride; ++i) {
+          cur[i] = (unsigned char)(in[i] + prev[i]);
+        }
+        break;
+      case 3:
+        for (size_t i = 0; i < B && i < stride; ++i) {
+          cur[i] = (unsigned char)(in[i] + (prev[i] >> 1));
+        }
+        for (size_t i = B; i < stride; ++i) {
+          cur[i] = (unsigned char)(in[i] + ((cur[i - B] + prev[i]) >> 1));
+        }
+        break;
+      case 4:
+        for (size_t i = 0; i < B && i < stride; ++i) {
+          cur[i] = (unsigned char)(in[i] + prev[i]);
+        }
+        for (size_t i = B; i < stride; ++i) {
+          const int a = cur[i - B], b = prev[i], c = prev[i - B];
+          const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+          cur[i] = (unsigned char)(in[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+        }
+        break;
+      default:
+        LOG_FATAL("bad PNG filter: " + path.string());
     }
     uint16_t* o = &img.px[(size_t)y * img.w * img.channels];
-    for (int i = 0; i < img.w * img.channels; ++i) {
-      o[i] = img.bitdepth == 16 ? uint16_t((cur[2 * i] << 8) | cur[2 * i + 1]) : cur[i];
+    const int nv = img.w * img.channels;
+    if (img.bitdepth == 16) {
+      for (int i = 0; i < nv; ++i) {
+        o[i] = uint16_t((cur[2 * i] << 8) | cur[2 * i + 1]);
+      }
+    } else {
+      for (int i = 0; i < nv; ++i) {
+        o[i] = cur[i];
+      }
     }
     prev.swap(cur);
   }
@@ -684,6 +718,22 @@ inline void write_png(const fs::path& path, const uint16_t* px, int w, int h, in
 }
 
 // cv_util::loadImage<Vec3w> (CvUtil.h:196-284): IMREAD_UNCHANGED -> 16U (8-bit x257) -> BGR
+// into a caller buffer of expectW x expectH x 3 (pinned staging memory of the CLI's I/O pipeline)
+inline void load_color_bgr16_into(const fs::path& path, uint16_t* out, int expectW, int expectH) {
+  const Png p = read_png(path);
+  CHECK_MSG(p.w == expectW && p.h == expectH, "image size mismatch: " + path.string());
+  const int mul = p.bitdepth == 8 ? 257 : 1;
+  const size_t n = (size_t)p.w * p.h;
+  for (size_t i = 0; i < n; ++i) {
+    if (p.channels == 1) {
+      out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = p.px[i] * mul;
+    } else {
+      out[3 * i + 0] = p.px[p.channels * i + 2] * mul;  // B
+      out[3 * i + 1] = p.px[p.channels * i + 1] * mul;  // G
+      out[3 * i + 2] = p.px[p.channels * i + 0] * mul;  // R
+    }
+  }
+}
 inline std::vector<uint16_t> load_color_bgr16(const fs::path& path, int& w, int& h) {
   const Png p = read_png(path);
   w = p.w;
@@ -773,6 +823,94 @@ inline void pyramid_level_sizes(std::map<int, std::pair<int, int>>& sizes, const
     }
   }
 }
+
+// I/O worker pool of the executables (--threads: -1 = one per hardware thread, 0 = run inline): PNG / PFM
+// decode and encode run here while the GPU computes. The reference spends --threads on the compute itself
+// (ThreadPool.h); here the compute is the GPU's.
+struct IoPool {
+  std::vector<std::thread> workers;
+  std::deque<std::function<void()>> queue;
+  std::mutex mu;
+  std::condition_variable cvWork, cvIdle;
+  int busy = 0;
+  bool stop = false;
+  explicit IoPool(int threads) {
+    int n = threads < 0 ? (int)std::thread::hardware_concurrency() : threads;
+    n = std::min(n, 64);
+    for (int i = 0; i < n; ++i) {
+      workers.emplace_back([this] {
+        for (;;) {
+          std::function<void()> job;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cvWork.wait(lk, [this] { return stop || !queue.empty(); });
+            if (queue.empty()) {
+              return;
+            }
+            job = std::move(queue.front());
+            queue.pop_front();
+            ++busy;
+          }
+          job();
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            --busy;
+          }
+          cvIdle.notify_all();
+        }
+      });
+    }
+  }
+  void submit(std::function<void()> job) {
+    if (workers.empty()) {
+      job();
+      return;
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      queue.push_back(std::move(job));
+    }
+    cvWork.notify_one();
+  }
+  void wait_idle() {
+    std::unique_lock<std::mutex> lk(mu);
+    cvIdle.wait(lk, [this] { return queue.empty() && busy == 0; });
+  }
+  ~IoPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cvWork.notify_all();
+    for (auto& t : workers) {
+      t.join();
+    }
+  }
+};
+// a batch of pool jobs that can be waited for on its own (frame f + 1 decoding while frame f's files are written)
+struct IoBatch {
+  std::mutex mu;
+  std::condition_variable cv;
+  int pending = 0;
+  void add(IoPool& pool, std::function<void()> job) {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      ++pending;
+    }
+    pool.submit([this, job] {
+      job();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        --pending;
+      }
+      cv.notify_all();
+    });
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return pending == 0; });
+  }
+};
 
 struct Timer {
   timespec t0;

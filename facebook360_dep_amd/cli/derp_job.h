@@ -1,0 +1,455 @@
+// What DerpCLI's main does around processLevel (source/depth_estimation/DerpCLI.cpp:69-218), shared by the
+// DerpCLI and DerpSequence executables: the flag table, input verification, rig and pyramid geometry, the
+// HIP context, and the I/O pipeline around the GPU (worker-pool PNG / PFM decode into page-locked staging
+// memory, uploads, downloads into page-locked memory, worker-pool file writes).
+#pragma once
+#include "cli_common.h"
+
+namespace cli {
+
+// DerpCLI.cpp:40-67 — names, defaults and descriptions are API (scripts scrape them, system_util.py:123-176)
+inline void define_derp_flags(Flags& F) {
+  F.str("background_disp", "", "path to background disparities");
+  F.str("background_frame", "000000", "background frame (lexical)");
+  F.str("cameras", "", "comma-separated destinations to render (empty for all)");
+  F.str("color", "", "path to input color images");
+  F.boolean("do_bilateral_filter", true, "apply bilateral filter at each level");
+  F.boolean("do_median_filter", true, "apply median filter to disparity at each level");
+  F.str("first", "000000", "first frame to process (lexical)");
+  F.str("foreground_masks", "", "path to foreground masks");
+  F.str("input_root", "", "path to input data (required)");
+  F.str("last", "000000", "last frame to process (lexical)");
+  F.i32("level_end", -1, "level to end at (-1 = finest)");
+  F.i32("level_start", -1, "level to start at (-1 = coarsest)");
+  F.dbl("max_depth_m", 1e4, "max depth (m)");
+  F.dbl("min_depth_m", .50, "min depth (m)");
+  F.i32("mismatches_start_level", -1, "(-1 = no mismatch handling)");
+  F.i32("num_levels", -1, "number of levels in the pyramid (-1 = uses highest level)");
+  F.str("output_formats", "", "saved formats, comma separated (exr, png, pfm supported)");
+  F.str("output_root", "", "path to output directory (required)");
+  F.boolean("partial_coverage", false, "set to true if no 360 coverage");
+  F.i32("ping_pong_iterations", 1, "number of spatial propagation iterations");
+  F.i32("random_proposals", 2, "number of proposed random disparities before propagation");
+  F.i32("resolution", 2048, "Output resolution (width in pixels)");
+  F.str("rig", "", "path to camera rig .json");
+  F.boolean("save_debug_images", false, "if true, save debugging output images");
+  F.i32("threads", -1,
+        "number of threads (-1 = auto, 0 = none) [here: image decode / file write workers; the compute is the GPU's]");
+  F.boolean("use_foreground_masks", false, "use pre-computed foreground masks");
+  F.dbl("var_high_thresh", 1e-3, "ignore variances higher than this threshold");
+  F.dbl("var_noise_floor", 4e-5, "noise variance floor on original, full-size images");
+  F.i32("device", 0, "HIP device index [extension]");
+}
+
+struct DerpJob {
+  Flags& F;
+  std::vector<derp_camera_desc> rigSrc, rigDst;
+  int S = 0, D = 0;
+  std::map<int, std::pair<int, int>> sizes;
+  int numLevels = 0, levelStart = 0, levelEnd = 0, firstFrame = 0, numFrames = 0;
+  bool useFg = false, savePng = false;
+  std::string inputRoot, outputRoot;
+  fs::path dispLevels;
+  std::vector<int> W, H;
+  int widthFull = 0, heightFull = 0;
+  derp_ctx* ctx = nullptr;
+
+  explicit DerpJob(Flags& f) : F(f) {}
+  static fs::path levelDir(const fs::path& base, int level) { return base / ("level_" + std::to_string(level)); }
+  size_t npx(int level) const { return (size_t)W[level] * H[level]; }
+
+  // verifyInputs + rig + pyramid geometry (DerpCLI.cpp:69-218); `device` overrides --device when >= 0
+  void setup(int device = -1) {
+    CHECK_MSG(F.s("input_root") != "", "input_root");
+    CHECK_MSG(F.s("output_root") != "", "output_root");
+    if (F.i("level_start") >= 0 && F.i("level_end") >= 0) {
+      CHECK_MSG(F.i("level_start") >= F.i("level_end"), "level_start >= level_end");
+    }
+    inputRoot = F.s("input_root");
+    outputRoot = F.s("output_root");
+    if (F.s("rig").empty()) {
+      F.set("rig", inputRoot + "/rigs/rig_calibrated.json");
+    }
+    if (F.s("color").empty()) {
+      F.set("color", inputRoot + "/video/color_levels");
+    }
+    if (F.s("background_disp").empty()) {
+      F.set("background_disp", inputRoot + "/background/disparity_levels");
+    }
+    if (F.s("foreground_masks").empty()) {
+      F.set("foreground_masks", inputRoot + "/video/foreground_masks_levels");
+    }
+    CHECK_MSG(F.i("random_proposals") >= 0, "random_proposals >= 0");
+    CHECK_MSG(F.s("first") <= F.s("last"), "first <= last");
+    CHECK_MSG(fs::is_directory(F.s("color")), "No images in " + F.s("color"));
+    useFg = F.b("use_foreground_masks");
+    if (useFg) {
+      CHECK_MSG(fs::is_directory(F.s("background_disp")),
+                "Asked to use background but no background disparities found in " + F.s("background_disp"));
+      CHECK_MSG(fs::is_directory(F.s("foreground_masks")),
+                "Asked to use foreground masks but no foreground masks found in " + F.s("foreground_masks"));
+    }
+    {
+      std::stringstream ss(F.s("output_formats"));
+      std::string f;
+      bool anyOther = false, exr = false;
+      while (std::getline(ss, f, ',')) {
+        CHECK_MSG(f.empty() || f == "exr" || f == "png" || f == "pfm", "Invalid output format specified: " + f);
+        savePng |= f == "png";
+        exr |= f == "exr";
+        anyOther |= f == "png" || f == "pfm";
+      }
+      // PyramidLevel.h:515-516 writes .exr through OpenCV; this build has no EXR encoder. Asking for exr ALONE
+      // fails loudly; next to png / pfm it is skipped with a warning (pfm is always written, like the reference)
+      CHECK_MSG(!exr || anyOther, "output format exr is not supported by this build (pfm and png are)");
+      if (exr) {
+        LOG_WARNING("exr output is not supported by this build; pfm is always written");
+      }
+      if (F.s("output_formats").empty()) {
+        LOG_WARNING("No explicit output formats specified. Forcing PFM...");
+      }
+    }
+    // ---- rig (DerpCLI.cpp:185-192)
+    rigSrc = load_rig(F.s("rig"));
+    CHECK_MSG(!rigSrc.empty(), "no source cameras!");
+    rigDst = filter_destinations(rigSrc, F.s("cameras"));
+    CHECK_MSG(!rigDst.empty(), "no destination cameras!");
+    S = (int)rigSrc.size();
+    D = (int)rigDst.size();
+    // ---- pyramid geometry (DerpCLI.cpp:194-215)
+    dispLevels = fs::path(outputRoot) / "disparity_levels";
+    pyramid_level_sizes(sizes, F.s("color"));
+    pyramid_level_sizes(sizes, dispLevels);
+    CHECK_MSG(!sizes.empty(), "No pyramid levels found in " + F.s("color"));
+    numLevels = F.i("num_levels") == -1 ? sizes.rbegin()->first + 1 : F.i("num_levels");
+    levelStart = F.i("level_start") >= 0 ? F.i("level_start") : numLevels - 1;
+    levelEnd = 0;
+    for (const auto& kv : sizes) {  // getLevelEnd, DerpCLI.cpp:158-177
+      if (kv.second.first <= F.i("resolution")) {
+        levelEnd = kv.first;
+        break;
+      }
+    }
+    if (F.i("level_end") >= 0) {
+      CHECK_MSG(F.i("level_end") >= levelEnd,
+                fmt("Requested end level %d, which is larger than requested resolution (%d)", F.i("level_end"),
+                    F.i("resolution")));
+    }
+    levelEnd = std::max(levelEnd, F.i("level_end"));
+    CHECK_MSG(F.i("level_start") <= numLevels, "level_start <= numLevels");
+    firstFrame = std::stoi(F.s("first"));
+    numFrames = std::stoi(F.s("last")) - firstFrame + 1;
+    // verifyInputImagePaths (DerpCLI.cpp:137-156)
+    verify_image_paths(levelDir(F.s("color"), levelStart), rigSrc, F.s("first"), F.s("last"));
+    if (useFg) {
+      verify_image_paths(levelDir(F.s("background_disp"), levelStart), rigDst, F.s("background_frame"),
+                         F.s("background_frame"));
+      verify_image_paths(levelDir(F.s("foreground_masks"), levelStart), rigDst, F.s("first"), F.s("last"));
+    }
+    if (levelStart < numLevels - 1) {
+      verify_image_paths(levelDir(dispLevels, levelStart + 1), rigDst, F.s("first"), F.s("last"));
+    }
+    fs::create_directories(outputRoot);
+    widthFull = (int)rigDst[0].resolution[0];
+    heightFull = (int)rigDst[0].resolution[1];
+    // ---- context
+    if (derp_create(&ctx, device >= 0 ? device : F.i("device"), rigSrc.data(), S, rigDst.data(), D) != 0) {
+      LOG_FATAL(std::string("derp_create failed: ") + derp_last_error(nullptr));
+    }
+    derp_options opt;
+    derp_options_default(&opt);
+    opt.min_depth_m = (float)F.d("min_depth_m");
+    opt.max_depth_m = (float)F.d("max_depth_m");
+    opt.var_noise_floor = (float)F.d("var_noise_floor");
+    opt.var_high_thresh = (float)F.d("var_high_thresh");
+    opt.random_proposals = F.i("random_proposals");
+    opt.ping_pong_iterations = F.i("ping_pong_iterations");
+    opt.mismatches_start_level = F.i("mismatches_start_level");
+    opt.do_bilateral_filter = F.b("do_bilateral_filter");
+    opt.do_median_filter = F.b("do_median_filter");
+    opt.use_foreground_masks = useFg;
+    opt.partial_coverage = F.b("partial_coverage");
+    opt.rebuild_warp_tables = 0;  // warps depend on rig + level size only: build once, reuse across frames
+    DERP_OK(ctx, derp_set_options(ctx, &opt));
+    // levels outside [levelEnd, min(levelStart + 1, numLevels - 1)] are declared absent (no HBM spent on them)
+    W.assign(numLevels, 0);
+    H.assign(numLevels, 0);
+    const int topLevel = std::min(levelStart + 1, numLevels - 1);
+    for (int l = levelEnd; l <= topLevel; ++l) {
+      CHECK_MSG(sizes.count(l), fmt("no images found for level %d", l));
+      W[l] = sizes[l].first;
+      H[l] = sizes[l].second;
+    }
+    DERP_OK(ctx, derp_set_pyramid(ctx, numLevels, W.data(), H.data(), widthFull, heightFull));
+  }
+
+  // createLevelOutputDirs (DerpUtil.cpp:311-330); `extra` = further per-level image types (time-filtered levels)
+  void create_output_dirs(const std::vector<std::string>& extra = {}) const {
+    for (int level = levelStart; level >= levelEnd; --level) {
+      for (const auto& cam : rigDst) {
+        fs::create_directories(fs::path(outputRoot) / "disparity" / cam.id);
+        fs::create_directories(levelDir(dispLevels, level) / cam.id);
+        for (const auto& t : extra) {
+          fs::create_directories(levelDir(fs::path(outputRoot) / t, level) / cam.id);
+        }
+        if (F.b("save_debug_images")) {
+          for (const char* t : {"cost", "confidence", "mismatches"}) {
+            fs::create_directories(levelDir(fs::path(outputRoot) / t, level) / cam.id);
+          }
+        }
+      }
+    }
+  }
+};
+
+// host memory the uploads / downloads go through: page-locked when the runtime grants it
+struct Arena {
+  void* p = nullptr;
+  bool pinned = false;
+  size_t bytes = 0;
+  void ensure(size_t n) {
+    if (n <= bytes) {
+      return;
+    }
+    release();
+    p = derp_host_alloc(n);
+    pinned = p != nullptr;
+    if (!p) {
+      p = malloc(n);
+    }
+    CHECK_MSG(p != nullptr, "out of host memory");
+    bytes = n;
+  }
+  void release() {
+    if (p) {
+      if (pinned) {
+        derp_host_free(p);
+      } else {
+        free(p);
+      }
+    }
+    p = nullptr;
+    bytes = 0;
+  }
+};
+
+// One frame's inputs (loadLevelImages, ImageUtil.h:79-94; DerpCLI.cpp:235-248,276-303): decoded by the pool into
+// one of two staging arenas, then uploaded into the context's SELECTED frame slot.
+struct FrameStager {
+  const DerpJob& J;
+  IoPool& pool;
+  int inTop;
+  std::map<int, size_t> offColor, offMask, offBg;
+  size_t inBytes = 0, offPrev = 0;
+  Arena arena[2];
+  IoBatch batch[2];
+  double waited = 0, uploading = 0;
+
+  FrameStager(const DerpJob& job, IoPool& p) : J(job), pool(p) {
+    // coarse masks feed the masked upsample (DerpCLI.cpp:280-285)
+    inTop = J.useFg && J.levelStart < J.numLevels - 1 ? J.levelStart + 1 : J.levelStart;
+    for (int level = inTop; level >= J.levelEnd; --level) {
+      if (level <= J.levelStart) {
+        offColor[level] = inBytes;
+        inBytes += J.npx(level) * 6 * J.S;
+      }
+      if (J.useFg) {
+        offMask[level] = inBytes;
+        inBytes += (J.npx(level) * J.S + 15) / 16 * 16;
+        if (level <= J.levelStart) {
+          offBg[level] = inBytes;
+          inBytes += J.npx(level) * 4 * J.D;
+        }
+      }
+    }
+    if (J.levelStart < J.numLevels - 1) {
+      offPrev = inBytes;
+      inBytes += J.npx(J.levelStart + 1) * 4 * J.D;
+    }
+  }
+  ~FrameStager() {
+    batch[0].wait();
+    batch[1].wait();
+    arena[0].release();
+    arena[1].release();
+  }
+
+  void start_decode(int frameNumber, int parity) {
+    const std::string frameName = zero_pad(frameNumber);
+    Arena& A = arena[parity];
+    A.ensure(inBytes);
+    char* base = static_cast<char*>(A.p);
+    IoBatch& B = batch[parity];
+    const DerpJob* j = &J;
+    const Flags& F = J.F;
+    for (int level = inTop; level >= J.levelEnd; --level) {
+      const int w = J.W[level], h = J.H[level];
+      for (int s = 0; s < J.S; ++s) {
+        if (level <= J.levelStart) {
+          uint16_t* dst = reinterpret_cast<uint16_t*>(base + offColor[level]) + J.npx(level) * 3 * s;
+          const fs::path path = image_path(DerpJob::levelDir(F.s("color"), level), J.rigSrc[s].id, frameName);
+          B.add(pool, [=] { load_color_bgr16_into(path, dst, w, h); });
+        }
+        if (J.useFg) {
+          uint8_t* dst = reinterpret_cast<uint8_t*>(base + offMask[level]) + J.npx(level) * s;
+          const fs::path path = image_path(DerpJob::levelDir(F.s("foreground_masks"), level), J.rigSrc[s].id, frameName);
+          B.add(pool, [=] {
+            int mw, mh;
+            const std::vector<uint8_t> m = load_mask(path, mw, mh);
+            CHECK_MSG(mw == w && mh == h, "mask size mismatch: " + path.string());
+            memcpy(dst, m.data(), m.size());
+          });
+        }
+      }
+      if (J.useFg && level <= J.levelStart) {
+        for (int d = 0; d < J.D; ++d) {
+          float* dst = reinterpret_cast<float*>(base + offBg[level]) + J.npx(level) * d;
+          const fs::path path = image_path(DerpJob::levelDir(F.s("background_disp"), level), J.rigDst[d].id,
+                                           F.s("background_frame"));
+          B.add(pool, [=] {
+            int bw, bh;
+            const std::vector<float> bg = load_float(path, bw, bh);
+            CHECK_MSG(bw == w && bh == h, "background disparity size mismatch: " + path.string());
+            memcpy(dst, bg.data(), bg.size() * 4);
+          });
+        }
+      }
+    }
+    if (J.levelStart < J.numLevels - 1) {  // resume: previous level from disk (DerpCLI.cpp:287-288)
+      const int level = J.levelStart + 1, w = J.W[level], h = J.H[level];
+      for (int d = 0; d < J.D; ++d) {
+        float* dst = reinterpret_cast<float*>(base + offPrev) + J.npx(level) * d;
+        const fs::path path = image_path(DerpJob::levelDir(j->dispLevels, level), J.rigDst[d].id, frameName, ".pfm");
+        B.add(pool, [=] {
+          int pw, ph;
+          const std::vector<float> prev = load_float(path, pw, ph);
+          CHECK_MSG(pw == w && ph == h, "previous-level disparity size mismatch: " + path.string());
+          memcpy(dst, prev.data(), prev.size() * 4);
+        });
+      }
+    }
+  }
+
+  void wait(int parity) {
+    Timer t;
+    batch[parity].wait();
+    waited += t.s();
+  }
+
+  // into the frame slot currently selected in the context
+  void upload(int parity) {
+    Timer t;
+    derp_ctx* ctx = J.ctx;
+    const char* base = static_cast<const char*>(arena[parity].p);
+    for (int level = inTop; level >= J.levelEnd; --level) {
+      for (int s = 0; s < J.S; ++s) {
+        if (level <= J.levelStart) {
+          DERP_OK(ctx, derp_upload_color(ctx, level, s,
+                                         reinterpret_cast<const uint16_t*>(base + offColor.at(level)) + J.npx(level) * 3 * s));
+        }
+        if (J.useFg) {
+          DERP_OK(ctx, derp_upload_foreground_mask(
+                           ctx, level, s, reinterpret_cast<const uint8_t*>(base + offMask.at(level)) + J.npx(level) * s));
+        }
+      }
+      if (J.useFg && level <= J.levelStart) {
+        for (int d = 0; d < J.D; ++d) {
+          DERP_OK(ctx, derp_upload_background_disparity(
+                           ctx, level, d, reinterpret_cast<const float*>(base + offBg.at(level)) + J.npx(level) * d));
+        }
+      }
+    }
+    if (J.levelStart < J.numLevels - 1) {
+      for (int d = 0; d < J.D; ++d) {
+        DERP_OK(ctx, derp_upload_disparity(ctx, J.levelStart + 1, d,
+                                           reinterpret_cast<const float*>(base + offPrev) + J.npx(J.levelStart + 1) * d));
+      }
+    }
+    uploading += t.s();
+  }
+};
+
+// saveResults (PyramidLevel.h:487-529): the selected frame's level is downloaded into page-locked memory and
+// written by the pool (PFM always, PNG on request) into every directory of `dirs`.
+struct LevelWriter {
+  const DerpJob& J;
+  IoPool& pool;
+  Arena arena[2];
+  IoBatch batch[2];
+  double waited = 0, downloading = 0;
+  LevelWriter(const DerpJob& job, IoPool& p) : J(job), pool(p) {}
+  ~LevelWriter() {
+    finish();
+    arena[0].release();
+    arena[1].release();
+  }
+  // make arena[parity] (>= bytes) available: the files written from it earlier are on disk
+  void begin(int parity, size_t bytes) {
+    Timer t;
+    batch[parity].wait();
+    waited += t.s();
+    arena[parity].ensure(bytes);
+  }
+  void save(int parity, size_t offset, int level, const std::string& frameName, const std::vector<fs::path>& dirs) {
+    derp_ctx* ctx = J.ctx;
+    const int w = J.W[level], h = J.H[level];
+    const bool png = J.savePng;
+    for (int d = 0; d < J.D; ++d) {
+      float* disp = reinterpret_cast<float*>(static_cast<char*>(arena[parity].p) + offset) + J.npx(level) * d;
+      {
+        Timer t;
+        DERP_OK(ctx, derp_download_disparity(ctx, level, d, disp));
+        downloading += t.s();
+      }
+      std::vector<fs::path> bases;
+      for (const auto& dir : dirs) {
+        bases.push_back(DerpJob::levelDir(dir, level) / J.rigDst[d].id);
+      }
+      batch[parity].add(pool, [=] {
+        for (const auto& base : bases) {
+          write_pfm(base / (frameName + ".pfm"), disp, w, h);
+          if (png) {
+            write_disparity_png(base / (frameName + ".png"), disp, w, h);
+          }
+        }
+      });
+    }
+  }
+  void finish() {
+    Timer t;
+    batch[0].wait();
+    batch[1].wait();
+    waited += t.s();
+  }
+};
+
+// debug images of the level processed last (PyramidLevel.h:418-485), written inline
+inline void save_debug_images(const DerpJob& J, int level, const std::string& frameName) {
+  derp_ctx* ctx = J.ctx;
+  const size_t n = J.npx(level);
+  for (int d = 0; d < J.D; ++d) {
+    std::vector<float> cost(n), conf(n);
+    DERP_OK(ctx, derp_download_cost(ctx, d, cost.data(), conf.data()));
+    for (auto& v : cost) {
+      v *= 255.0f / 100.0f / 65535.0f * 257.0f;  // kScaleCostPlot, 8-bit range in a 16-bit file
+    }
+    write_disparity_png(DerpJob::levelDir(fs::path(J.outputRoot) / "cost", level) / J.rigDst[d].id / (frameName + ".png"),
+                        cost.data(), J.W[level], J.H[level]);
+    for (auto& v : conf) {
+      v *= 255.0f * 100.0f / 65535.0f * 257.0f;  // kScaleConfidencePlot
+    }
+    write_disparity_png(
+        DerpJob::levelDir(fs::path(J.outputRoot) / "confidence", level) / J.rigDst[d].id / (frameName + ".png"),
+        conf.data(), J.W[level], J.H[level]);
+    std::vector<uint8_t> mm(n);
+    DERP_OK(ctx, derp_download_mismatch_mask(ctx, d, mm.data()));
+    std::vector<uint16_t> mpx(n);
+    for (size_t i = 0; i < n; ++i) {
+      mpx[i] = mm[i] ? 255 : 0;
+    }
+    write_png(DerpJob::levelDir(fs::path(J.outputRoot) / "mismatches", level) / J.rigDst[d].id / (frameName + ".png"),
+              mpx.data(), J.W[level], J.H[level], 1, 8);
+  }
+}
+
+}  // namespace cli

@@ -1168,6 +1168,20 @@ int derp_frame_slots(const derp_ctx* c, int* n_slots, int* selected) {
   return 0;
 }
 
+void* derp_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void derp_host_free(void* p) {
+  if (p) {
+    (void)hipHostFree(p);
+  }
+}
+
 int derp_upload_color(derp_ctx* c, int level, int s, const uint16_t* bgr) {
   TRY(check_level(c, level));
   if (s < 0 || s >= c->S || !bgr) {

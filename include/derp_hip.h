@@ -94,6 +94,13 @@ int derp_set_frame_slots(derp_ctx* ctx, int n_slots);
 int derp_select_frame(derp_ctx* ctx, int slot);
 int derp_frame_slots(const derp_ctx* ctx, int* n_slots, int* selected);
 
+/* ---- host staging memory ----------------------------------------------------------------------
+ * Page-locked host memory for the buffers handed to derp_upload_* / derp_download_*: the copies then run
+ * at PCIe rate instead of through the runtime's pageable bounce buffers. Optional: any host pointer works.
+ * derp_host_alloc returns NULL on failure (callers fall back to malloc). */
+void* derp_host_alloc(size_t bytes);
+void derp_host_free(void* p);
+
 /* ---- inputs (loadLevelImages, ImageUtil.h:79-94; DerpCLI.cpp:235-248,276-303) ------------ */
 int derp_upload_color(derp_ctx* ctx, int level, int src, const uint16_t* bgr);
 int derp_upload_foreground_mask(derp_ctx* ctx, int level, int src, const uint8_t* mask);

@@ -150,6 +150,66 @@ def test_temporal_cli(dataset, tmp_path):
             assert bad == 0, (cur, cam, bad, rel)
 
 
+def test_derp_sequence_cli_equals_the_three_binary_pipeline(dataset, tmp_path):
+    """The depth_estimation stage of scripts/render/pipeline.py:364-408 two ways: (a) the way the reference
+    orchestrates it — per level, DerpCLI on every frame, TemporalBilateralFilter on every frame, then "Transfer"
+    (copy the filtered level over disparity_levels) — with this build's drop-in binaries and the file system in
+    between; (b) bin/DerpSequence, which keeps the frames resident in HBM and fuses the three. Same files,
+    bit for bit; and both equal the oracle's run of the schedule."""
+    import shutil
+
+    from facebook360_dep_amd import imageio as dio
+    from facebook360_dep_amd import sequence
+
+    root = dataset["root"]
+    rigf = os.path.join(root, "rigs", "rig_calibrated.json")
+    ids = [c["id"] for c in dataset["rig"]["cameras"]]
+    n_levels = len(dataset["sizes"])
+    common_flags = ["--input_root=" + root, "--first=000000", "--last=000002", "--partial_coverage", "--resolution=96"]
+    # (a) three binaries + Transfer, level by level
+    out_a = str(tmp_path / "a")
+    for level in range(n_levels - 1, -1, -1):
+        run("DerpCLI", *common_flags, "--output_root=" + out_a, "--level_start=%d" % level, "--level_end=%d" % level)
+        run("TemporalBilateralFilter", "--input_root=" + root, "--output_root=" + out_a, "--rig=" + rigf,
+            "--first=000000", "--last=000002", "--level=%d" % level)
+        src = os.path.join(out_a, "disparity_time_filtered_levels", "level_%d" % level)
+        dst = os.path.join(out_a, "disparity_levels", "level_%d" % level)
+        shutil.rmtree(dst)
+        shutil.copytree(src, dst)
+    # (b) fused
+    out_b = str(tmp_path / "b")
+    p = run("DerpSequence", *common_flags, "--output_root=" + out_b)
+    assert "-- TOTAL:" in p.stderr and "3 frame(s) owned, 0 halo" in p.stderr
+    ref = common.OracleSequence(dataset["rig"], dataset["sizes"], dataset["res"], 0, 2, threads=-1)
+    sequence.run_schedule(ref, list(range(n_levels - 1, -1, -1)), 0, 2, 0, 1)
+    for level in range(n_levels):
+        for d, cam in enumerate(ids):
+            for f in range(3):
+                name = os.path.join("level_%d" % level, cam, "%06d.pfm" % f)
+                a = open(os.path.join(out_a, "disparity_levels", name), "rb").read()
+                b = open(os.path.join(out_b, "disparity_levels", name), "rb").read()
+                assert a == b, name
+                assert b == open(os.path.join(out_b, "disparity_time_filtered_levels", name), "rb").read()
+                got = dio.read_pfm(os.path.join(out_b, "disparity_levels", name))
+                want = ref.disp[f][level][d].numpy()
+                assert common.compare_disparity(got, want, 1e-4)[0] == 0, name
+    # without the temporal filter DerpSequence degenerates to DerpCLI
+    out_c = str(tmp_path / "c")
+    run("DerpSequence", *common_flags, "--output_root=" + out_c, "--do_temporal_filter=false")
+    out_d = str(tmp_path / "d")
+    run("DerpCLI", *common_flags, "--output_root=" + out_d)
+    name = os.path.join("disparity_levels", "level_0", ids[1], "000001.pfm")
+    assert open(os.path.join(out_c, name), "rb").read() == open(os.path.join(out_d, name), "rb").read()
+    assert not os.path.exists(os.path.join(out_c, "disparity_time_filtered_levels", "level_0", ids[1], "000001.pfm"))
+
+
+def test_output_format_exr_alone_is_refused(dataset, tmp_path):
+    """PyramidLevel.h:515-516 writes .exr through OpenCV; this build has no EXR encoder and says so."""
+    p = run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "o"), "--partial_coverage",
+            "--resolution=96", "--output_formats=exr", expect_ok=False)
+    assert p.returncode != 0 and "exr is not supported" in p.stderr
+
+
 def test_upsample_cli(dataset, tmp_path):
     """BASELINE config 5's last step: UpsampleDisparity with colour guide, with and without masks."""
     from facebook360_dep_amd import imageio as dio

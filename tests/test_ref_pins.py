@@ -38,12 +38,15 @@ def _helpxml(binary):
     return flags
 
 
-@pytest.mark.parametrize("binary", ["DerpCLI", "TemporalBilateralFilter", "UpsampleDisparity", "LayerDisparities",
-                                    "GenerateForegroundMasks", "ComputeRephotographyErrors"])
-def test_flag_tables_match_the_reference(built, binary):
+@pytest.mark.parametrize("binary,ref_binary", [
+    ("DerpCLI", "DerpCLI"), ("TemporalBilateralFilter", "TemporalBilateralFilter"),
+    ("UpsampleDisparity", "UpsampleDisparity"), ("LayerDisparities", "LayerDisparities"),
+    ("GenerateForegroundMasks", "GenerateForegroundMasks"), ("ComputeRephotographyErrors", "ComputeRephotographyErrors"),
+    ("DerpSequence", "DerpCLI")])  # the fused sequence driver takes every DerpCLI flag unchanged
+def test_flag_tables_match_the_reference(built, binary, ref_binary):
     """Every DEFINE_* of the reference binary exists here with the same name, type, default and
     description (scripts read them: system_util.py:123-176, res/flags/*.flags)."""
-    ref = _gold("ref_flags.json")[binary]["flags"]
+    ref = _gold("ref_flags.json")[ref_binary]["flags"]
     mine = _helpxml(binary)
     assert len(ref) >= 9
     type_of = {"string": "string", "integer": "int32", "float": "double", "boolean": "bool"}
@@ -65,7 +68,14 @@ def test_flag_tables_match_the_reference(built, binary):
     ref_names = {f["name"] for f in ref}
     for name, got in mine.items():
         if name not in ref_names:
-            assert "[extension]" in got["meaning"] or got["meaning"].startswith("glog:"), (binary, name)
+            assert "[extension" in got["meaning"] or got["meaning"].startswith("glog:"), (binary, name)
+
+
+def test_derp_sequence_filter_flags_default_like_temporal_bilateral_filter(built):
+    ref = {f["name"]: f for f in _gold("ref_flags.json")["TemporalBilateralFilter"]["flags"]}
+    mine = _helpxml("DerpSequence")
+    for name in ("sigma", "space_radius", "time_radius", "weight_b", "weight_g", "weight_r"):
+        assert float(mine[name]["default"]) == float(ref[name]["default"]), name
 
 
 def test_level_sizes_match_config_and_resize_py():
