@@ -4,7 +4,7 @@
 Workload (the same for every --gpus N, so 1/2/4/8 is ONE scaling curve — strong scaling): BASELINE
 config 3, an 8-frame sequence of the 16-camera 2048^2 synthetic rig with the per-level temporal filter
 (scripts/render/pipeline.py:364-408). A step = the whole sequence, coarse to fine: for every level, every
-frame's processLevel (projection tables rebuilt per frame, colour reprojection, brute force, random
+frame's processLevel (projection warps built once per level, colour tables per frame, colour reprojection, brute force, random
 proposals, ping-pong, bilateral, median, FOV mask, upsample hand-off), the exchange of the halo frames' raw
 level disparity between ranks, the temporal filter and the write-back. Frames are sharded over the ranks in
 contiguous chunks (8/N frames per GPU); the exchange is RCCL send/recv issued by the library on its own
@@ -48,8 +48,8 @@ def parse():
     ap.add_argument("--exchange", default="rccl,torch,broadcast",
                     help="transports to try for the halo exchange, in order")
     ap.add_argument("--cache-warp-tables", type=int, default=0,
-                    help="1 = keep the rig-only projection warps across frames (default 0: rebuilt for every frame "
-                         "and level, as the reference does)")
+                    help="1 = keep the rig-only projection warps across steps too (default 0: every step rebuilds them "
+                         "once per level; the frames of a level on one rank share them)")
     return ap.parse_args()
 
 
@@ -288,7 +288,8 @@ def main():
             "temporal_filter": temporal,
             "halo_transport": transport,
             "halo_exchange": exch,
-            "warp_tables": "cached" if args.cache_warp_tables else "rebuilt for every frame and level",
+            "warp_tables": ("cached across steps" if args.cache_warp_tables else
+                            "rebuilt once per level per step, shared by the frames of the level on a rank (rig-only data)"),
             "parallelism": "frames x%d" % world,
         },
         "per_gpu_value": round(value / world, 3),

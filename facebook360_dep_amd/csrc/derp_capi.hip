@@ -114,6 +114,7 @@ struct derp_ctx {
   };
   std::vector<FrameSlot> parked;  // parked[curSlot] is empty while that slot is selected
   int curSlot = 0;
+  int xcdRotate = 1;
 
   // working level
   int cur = -1;
@@ -237,6 +238,7 @@ LevelView make_view(derp_ctx* c, int stage, int dst0, int nd) {
   V.maxDepthM = c->opt.max_depth_m;
   V.randomProposals = c->opt.random_proposals;
   V.partialCoverage = c->opt.partial_coverage;
+  V.xcdRotate = c->xcdRotate;
   V.camsSrc = c->camsSrc.as<Cam>();
   V.camsDst = c->camsDst.as<Cam>();
   V.dst2src = c->dst2src.as<int>();
@@ -976,6 +978,9 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
     return bail("hipSetDevice failed");
   }
   c->device = device;
+  if (const char* e = getenv("DERP_XCD_ROTATE")) {
+    c->xcdRotate = atoi(e);
+  }
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
     return bail("hipStreamCreate failed");
   }

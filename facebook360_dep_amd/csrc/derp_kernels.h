@@ -53,6 +53,7 @@ struct LevelView {
   float minDepthM, maxDepthM;
   int randomProposals;
   int partialCoverage;
+  int xcdRotate;              // rotate the XCD -> band map per destination (load balance)
   const Cam* camsSrc;         // [S] normalised
   const Cam* camsDst;         // [Dtotal] normalised
   const int* dst2src;         // [Dtotal]
@@ -85,9 +86,12 @@ __device__ __forceinline__ int slot(int s, int own) {
 
 // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give block b
 // the tile (b % 8) * ceil(n/8) + b / 8 — each XCD's L2 then serves one contiguous band.
-__device__ __forceinline__ int xcd_swizzle(int b, int n) {
+// `rot` rotates which band an XCD gets (callers pass the destination index): the top and bottom bands of
+// every image hold the clipped FOV-circle corners, i.e. less work, and without the rotation the same two
+// XCDs would draw them for every destination of the launch and idle at its end.
+__device__ __forceinline__ int xcd_swizzle(int b, int n, int rot) {
   const int per = (n + 7) >> 3;
-  const int t = (b & 7) * per + (b >> 3);
+  const int t = (((b & 7) + rot) & 7) * per + (b >> 3);
   return t;
 }
 
@@ -938,7 +942,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int dl = blockIdx.y;
   const int d = V.dst0 + dl;
   int x, y;
-  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x), tilesX, x, y);
+  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0), tilesX, x, y);
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
   unsigned nCost = 0, nPair = 0;
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
@@ -999,7 +1003,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int dl = blockIdx.y;
   const int d = V.dst0 + dl;
   int x, y;
-  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x), tilesX, x, y);
+  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0), tilesX, x, y);
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
   unsigned nCost = 0, nPair = 0, nMemo = 0;
   if (x < V.W && y < V.H) {

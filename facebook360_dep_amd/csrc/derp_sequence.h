@@ -606,10 +606,20 @@ int derp_seq_level_compute(derp_seq* q, int level) {
   }
   derp_ctx* c = q->c;
   HIPCHK(c, hipSetDevice(c->device));
-  for (int k = 0; k < (int)q->owned.size(); ++k) {
-    TRY(select_frame(c, k));
-    TRY(process_level(c, level));
+  // the projection warps depend on the rig and the level size only (precomputeProjections, Derp.cpp:955-976):
+  // the first frame of the level builds them (always, when rebuild_warp_tables asks for the reference's
+  // per-invocation rebuild), the other frames of the level reuse them
+  const int rebuild = c->opt.rebuild_warp_tables;
+  int rc = 0;
+  for (int k = 0; k < (int)q->owned.size() && !rc; ++k) {
+    rc = select_frame(c, k);
+    if (!rc) {
+      c->opt.rebuild_warp_tables = k == 0 ? rebuild : 0;
+      rc = process_level(c, level);
+    }
   }
+  c->opt.rebuild_warp_tables = rebuild;
+  TRY(rc);
   q->levelReady = level;
   return 0;
 }

@@ -143,6 +143,7 @@ class SequenceRunner:
         self._mode = "p2p"
         self._stage = False
         self._pending = []
+        self._received = 0  # bytes moved by the external (torch.distributed) transports
 
     def _frames(self, halo, n):
         buf = (C.c_int * max(n, 1))()
@@ -248,10 +249,18 @@ class SequenceRunner:
 
         for name in prefer:
             ok, why = True, ""
+            ident = [None]
+            if name == "rccl":  # every rank takes part in the broadcast even when rank 0 could not make an id
+                if self.rank == 0:
+                    try:
+                        ident = [rccl_unique_id()]
+                    except Exception as e:  # noqa: BLE001
+                        why = str(e)
+                dist.broadcast_object_list(ident, src=0)
             try:
                 if name == "rccl":
-                    ident = [rccl_unique_id() if self.rank == 0 else None]
-                    dist.broadcast_object_list(ident, src=0)
+                    if ident[0] is None:
+                        raise RuntimeError(why or "rank 0 could not create an RCCL unique id")
                     self.attach_rccl(ident[0])
                     self.selftest()
                 else:
@@ -313,17 +322,19 @@ class SequenceRunner:
         if self.transport in ("local", "rccl"):
             self._ck(derp.lib().derp_seq_run(self.h, level_start, level_end))
         elif self.transport in ("torch", "broadcast"):
-            run_schedule(self, range(level_start, level_end - 1, -1), self.first, self.last, self.rank, self.world,
-                         self.opt.time_radius, self.opt.partition, self._dist, self._mode)
+            self._received += run_schedule(self, range(level_start, level_end - 1, -1), self.first, self.last,
+                                           self.rank, self.world, self.opt.time_radius, self.opt.partition,
+                                           self._dist, self._mode)
         else:
             raise RuntimeError("transport %r needs the phases driven by the caller" % self.transport)
 
     def stats(self):
         a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
         self._ck(derp.lib().derp_seq_stats(self.h, C.byref(a), C.byref(b), C.byref(ms)))
-        return dict(bytes_sent=a.value, bytes_received=b.value, exchange_ms=ms.value)
+        return dict(bytes_sent=a.value, bytes_received=b.value + self._received, exchange_ms=ms.value)
 
     def stats_reset(self):
+        self._received = 0
         self._ck(derp.lib().derp_seq_stats_reset(self.h))
 
 

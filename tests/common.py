@@ -88,7 +88,7 @@ class OracleSequence:
     `sequence.SequenceRunner` over the HIP library)."""
 
     def __init__(self, rig, sizes, res, first, last, rank=0, world=1, radius=2, partition=0, threads=2,
-                 use_foreground_masks=False, **opts):
+                 use_foreground_masks=False, frames=None, **opts):
         import torch
 
         from facebook360_dep_amd import sequence, synth
@@ -99,8 +99,10 @@ class OracleSequence:
         self.n = len(rig["cameras"])
         self.owned = sequence.owned_frames(first, last, world, rank, partition)
         self.halo = sequence.halo_frames(first, last, world, rank, radius, partition) if world > 1 else []
-        self.frames = {t: synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu",
-                                           with_masks=use_foreground_masks) for t in self.owned}
+        # `frames` = {frame number: synth.make_frame dict} when the caller already rendered them
+        self.frames = {t: (frames[t] if frames is not None else
+                           synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu",
+                                            with_masks=use_foreground_masks)) for t in self.owned}
         # [frame][level] tensors; owned colour comes from the rendered frame, halo buffers start empty
         self.color, self.disp, self.fg = {}, {}, {}
         for t in self.owned + self.halo:

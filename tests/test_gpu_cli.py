@@ -180,7 +180,8 @@ def test_derp_sequence_cli_equals_the_three_binary_pipeline(dataset, tmp_path):
     out_b = str(tmp_path / "b")
     p = run("DerpSequence", *common_flags, "--output_root=" + out_b)
     assert "-- TOTAL:" in p.stderr and "3 frame(s) owned, 0 halo" in p.stderr
-    ref = common.OracleSequence(dataset["rig"], dataset["sizes"], dataset["res"], 0, 2, threads=-1)
+    ref = common.OracleSequence(dataset["rig"], dataset["sizes"], dataset["res"], 0, 2, threads=-1,
+                                frames={f: dataset["frames"][f] for f in range(3)})
     sequence.run_schedule(ref, list(range(n_levels - 1, -1, -1)), 0, 2, 0, 1)
     for level in range(n_levels):
         for d, cam in enumerate(ids):
