@@ -22,17 +22,19 @@ cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
 src, dst = "gpurun_out", "profiles"
 N_SIMD = 1024
 N_XCD = 8
-rows = list(csv.reader(open(os.path.join(src, tag + "_kernel_stats_full.csv"))))
+stats_path = os.path.join(src, tag + "_kernel_stats_full.csv")
+rows = list(csv.reader(open(stats_path))) if os.path.exists(stats_path) else [["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]]
 hdr, body = rows[0], rows[1:]
 keep = [r for r in body if "derp::" in r[0]]  # templates print as "void derp::k<...>(...)"
 other = [r for r in body if "derp::" not in r[0]]
-with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
-    w = csv.writer(f)
-    w.writerow(hdr)
-    for r in keep:
-        w.writerow(r)
-    w.writerow(["(non-derp kernels: torch synthetic-input rendering / copies / RCCL, outside the depth path)",
-                sum(int(r[1]) for r in other), sum(int(r[2]) for r in other), "", "", "", "", ""])
+if body:
+    with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(hdr)
+        for r in keep:
+            w.writerow(r)
+        w.writerow(["(non-derp kernels: torch synthetic-input rendering / copies / RCCL, outside the depth path)",
+                    sum(int(r[1]) for r in other), sum(int(r[2]) for r in other), "", "", "", "", ""])
 pm = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ISSUE", "SQ_INSTS"):
     path = os.path.join(src, "%s_pmc_%s.json" % (tag, c))

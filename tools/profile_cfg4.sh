@@ -1,0 +1,16 @@
+#!/bin/bash
+# BASELINE config 4 (24 x 4096^2, single frame, destinations batched under the table budget): bench line +
+# HBM traffic passes -> gpurun_out/r02cfg4_* (tools/make_profiles.py r02cfg4 cfg4 trims them into profiles/)
+tag=r02cfg4
+ARGS="--config cfg4 --frames 1 --temporal 0 --no-cpu-baseline --no-single-frame"
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+python bench.py --steps 2 --warmup 1 $ARGS > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pmc_$c
+  rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> gpurun_out/${tag}_pmc_$c.err
+  python tools/pmc_summarize.py /tmp/pmc_$c gpurun_out/${tag}_pmc_$c.json
+done
+rm -rf /tmp/pmc_SQ
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_SQ -o p -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> gpurun_out/${tag}_pmc_SQ_ISSUE.err
+python tools/pmc_summarize.py /tmp/pmc_SQ gpurun_out/${tag}_pmc_SQ_ISSUE.json
