@@ -200,6 +200,8 @@ def main():
     kernel_ms = pp["ms"] / launches
     memo = g.profile_memoised("ping_pong", 0) / launches
     stage_ms = {s: round(g.profile_query(s)["ms"] / args.steps, 3) for s in derp.STAGES}
+    level_ms = [round(sum(g.profile_query(s, lv)["ms"] for s in derp.STAGES) / args.steps / max(len(runner.owned), 1), 3)
+                for lv in range(n_levels)]
     cnt = g.counters()
     xs = runner.stats()
     exch = {"bytes_received_per_step": xs["bytes_received"] // max(args.steps, 1),
@@ -296,6 +298,7 @@ def main():
         "ms_per_frame": round(dt / args.steps / args.frames * 1e3 * world, 3),
         "roofline": roofline,
         "stage_ms_per_step": stage_ms,
+        "level_ms_per_frame": level_ms,  # all stages of one level of one frame (this rank), finest level first
         "input_upload": {"bytes": upload_bytes, "seconds": round(upload_s, 3),
                          "note": "host->HBM staging of this rank's colour pyramids, outside the timed region"},
         "device": g.device_name(),
