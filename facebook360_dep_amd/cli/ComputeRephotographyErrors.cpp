@@ -1,12 +1,13 @@
-// ComputeRephotographyErrors — stands in for source/render/ComputeRephotographyErrors.cpp, the
-// reference's quality gate for DerpCLI (scripts/test/test_derp_cli.py:64-100 expects 90 % +- 5 %):
-// same flags (:42-50), same log lines ("<cam> MSSIM: R ..%, G ..%, B ..%", "<frame> average ...",
-// "TOTAL average MSSIM: R ..%, G ..%, B ..%" as the last line of <log_dir>/<program>.INFO), plots under
-// <output>/rephoto/<cam>/<frame>.png.
-// Difference, by construction: the reference compares OpenGL cubemaps of disparity meshes centred on
-// each camera (CanopyScene); this build has no OpenGL renderer, so both sides live in the camera's own
-// image: reference = the camera's colour where its disparity is valid, rendered = derp_rephotograph
-// of all the other cameras. The score arithmetic (derp_ssim / derp_average_score) is the reference's.
+// ComputeRephotographyErrors — drop-in for source/render/ComputeRephotographyErrors.cpp, the reference's
+// quality gate for DerpCLI (scripts/test/test_derp_cli.py:64-100 expects 90 % +- 5 %): same flags (:42-50),
+// same log lines ("<cam> MSSIM: R ..%, G ..%, B ..%", "<frame> average ...", "TOTAL average MSSIM: R ..%,
+// G ..%, B ..%" as the last line of <log_dir>/<program>.INFO), plots under <output>/rephoto/<cam>/<frame>.png.
+// For every camera i, two cubemaps centred on it are rendered from disparity meshes — the camera alone, and all
+// the other cameras (generateCubemaps, :77-95) — by derp_canopy_cubemap, a HIP software rasteriser with
+// CanopyScene's pipeline (the reference uses OpenGL; what GL leaves implementation-defined is fixed in
+// DESIGN.md §8), and compared with the reference's score arithmetic (derp_ssim / derp_average_score) under the
+// reference cubemap's alpha mask. The second cubemap pair of the reference (disparity colours) only feeds its
+// plot and is not rendered.
 #include "cli_common.h"
 
 using namespace cli;
@@ -102,7 +103,6 @@ int main(int argc, char** argv) {
       }
       colors[i].swap(img);
     }
-    const size_t n = (size_t)w * h;
     std::vector<const uint16_t*> cp(rig.size());
     std::vector<const float*> dp(rig.size());
     for (size_t i = 0; i < rig.size(); ++i) {
@@ -112,52 +112,59 @@ int main(int argc, char** argv) {
     DERP_OK(ctx, derp_rephotograph_upload(ctx, cp.data(), dp.data(), w, h));
     double frameScore[3] = {0, 0, 0};
     int used = 0;
+    const int E = h;  // cubeHeight = colors[0].rows (ComputeRephotographyErrors.cpp:126)
+    const size_t nc = (size_t)6 * E * E;
     for (size_t i = 0; i < rig.size(); ++i) {
       const std::string camId = rig[i].id;
       if (!only.empty() && std::find(only.begin(), only.end(), camId) == only.end()) {
         continue;
       }
       LOG_INFO("Processing " + frame + " - " + camId + "...");
-      std::vector<float> rendered(n * 4);
-      DERP_OK(ctx, derp_rephotograph_render(ctx, (int)i, rendered.data()));
-      // reference side: own colour in [0, 1]; mask = own disparity valid (the cubemap's alpha > 0)
-      std::vector<float> x(n * 3), y(n * 3);
-      std::vector<uint8_t> mask(n);
-      const float s = 1.0f / 65535.0f;
-      for (size_t k = 0; k < n; ++k) {
-        const float d = disps[i][k];
-        mask[k] = (d > 0) && !std::isinf(d);
+      // cubesRef = generateCubemaps({rig[i]}, ...), cubesRender = generateCubemaps(removeOne(i, rig), ...), both
+      // seen from camera i's position (:137-145)
+      std::vector<uint8_t> onlyI(rig.size(), 0), allButI(rig.size(), 1);
+      onlyI[i] = 1;
+      allButI[i] = 0;
+      std::vector<float> cubeRef(nc * 4), cubeRender(nc * 4);
+      DERP_OK(ctx, derp_canopy_cubemap(ctx, onlyI.data(), rig[i].origin, E, cubeRef.data()));
+      DERP_OK(ctx, derp_canopy_cubemap(ctx, allButI.data(), rig[i].origin, E, cubeRender.data()));
+      // mask = 255 * (alpha > 0) of the reference cubemap; removeAlpha on both (:147-155)
+      std::vector<float> x(nc * 3), y(nc * 3);
+      std::vector<uint8_t> mask(nc);
+      for (size_t k = 0; k < nc; ++k) {
+        mask[k] = cubeRef[4 * k + 3] > 0;
         for (int c = 0; c < 3; ++c) {
-          x[3 * k + c] = mask[k] ? colors[i][3 * k + c] * s : 0.0f;  // zeroOutNans'd, alpha-less reference
-          y[3 * k + c] = rendered[4 * k + c];
+          x[3 * k + c] = cubeRef[4 * k + c];
+          y[3 * k + c] = cubeRender[4 * k + c];
         }
       }
-      std::vector<float> score(n * 3);
-      DERP_OK(ctx, derp_ssim(ctx, x.data(), y.data(), w, h, F.i("stat_radius"), abg, abg, 1.0f, score.data()));
+      std::vector<float> score(nc * 3);
+      DERP_OK(ctx, derp_ssim(ctx, x.data(), y.data(), E, 6 * E, F.i("stat_radius"), abg, abg, 1.0f, score.data()));
       double avg[3];
-      CHECK_MSG(derp_average_score(score.data(), mask.data(), w, h, avg) == 0, "derp_average_score");
+      CHECK_MSG(derp_average_score(score.data(), mask.data(), E, 6 * E, avg) == 0, "derp_average_score");
       LOG_INFO(camId + " " + method + ": " + format_results(avg));
       for (int c = 0; c < 3; ++c) {
         frameScore[c] += avg[c];
       }
       ++used;
-      // plot: reference | rendered (masked) | score, 8 bit, side by side (stackResults without the
-      // colour map and the caption)
-      std::vector<uint16_t> plot((size_t)3 * w * h * 3);
+      // plot: reference | rendered | score cubemaps side by side, 8 bit (stackResults without the colour map
+      // and the caption)
+      const int pw = 3 * E, ph = 6 * E;
+      std::vector<uint16_t> plot((size_t)pw * ph * 3);
       auto to8 = [](float v) { return (uint16_t)(v <= 0 ? 0 : v >= 1 ? 255 : lrintf(v * 255.0f)); };
-      for (int yy = 0; yy < h; ++yy) {
-        for (int xx = 0; xx < w; ++xx) {
-          const size_t k = (size_t)yy * w + xx;
+      for (int yy = 0; yy < ph; ++yy) {
+        for (int xx = 0; xx < E; ++xx) {
+          const size_t k = (size_t)yy * E + xx;
           for (int c = 0; c < 3; ++c) {
             const int rgb = 2 - c;  // write_png takes RGB
-            plot[((size_t)yy * 3 * w + xx) * 3 + rgb] = to8(x[3 * k + c]);
-            plot[((size_t)yy * 3 * w + w + xx) * 3 + rgb] = mask[k] ? to8(y[3 * k + c]) : 0;
+            plot[((size_t)yy * pw + xx) * 3 + rgb] = to8(x[3 * k + c]);
+            plot[((size_t)yy * pw + E + xx) * 3 + rgb] = mask[k] ? to8(y[3 * k + c]) : 0;
             const float sc = score[3 * k + c];
-            plot[((size_t)yy * 3 * w + 2 * w + xx) * 3 + rgb] = mask[k] && sc == sc ? to8(sc) : 0;
+            plot[((size_t)yy * pw + 2 * E + xx) * 3 + rgb] = mask[k] && sc == sc ? to8(sc) : 0;
           }
         }
       }
-      write_png(rephotoDir / camId / (frame + ".png"), plot.data(), 3 * w, h, 3, 8);
+      write_png(rephotoDir / camId / (frame + ".png"), plot.data(), pw, ph, 3, 8);
     }
     const int nCams = !only.empty() ? (int)only.size() : (int)rig.size();
     (void)used;

@@ -1765,6 +1765,58 @@ int derp_rephotograph(derp_ctx* c, int target, const uint16_t* const* colors, co
   return derp_rephotograph_render(c, target, out_bgra);
 }
 
+// CanopyScene::cubemap for the cameras `include[s] != 0` of the last derp_rephotograph_upload, seen from
+// `centre` (rig space): BGRA float [6 * edge][edge] (ComputeRephotographyErrors.cpp:77-95 generateCubemaps)
+int derp_canopy_cubemap(derp_ctx* c, const uint8_t* include, const double* centre, int edge, float* out_bgra) {
+  if (!c || !include || !centre || !out_bgra || edge < 1 || edge > 8192) {
+    return fail(c, "bad arguments");
+  }
+  if (c->rephotoW <= 0) {
+    return fail(c, "derp_rephotograph_upload has not been called");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const int w = c->rephotoW, h = c->rephotoH, E = edge;
+  const size_t n = (size_t)w * h, nf = (size_t)E * E;
+  DevBuf vert, rgba, zbuf, acc, out;
+  int rc = 0;
+  if (vert.ensure(n * 16) || rgba.ensure(n * 16) || zbuf.ensure(nf * 8) || acc.ensure(nf * 16) || out.ensure(nf * 6 * 16)) {
+    rc = fail(c, "out of device memory");
+  } else {
+    const float cx = (float)centre[0], cy = (float)centre[1], cz = (float)centre[2];  // position.cast<float>()
+    // meshes are needed once per camera, faces reuse them: camera-outer would redo the accumulation order, so keep
+    // the reference's order (face-outer, camera-inner) and rebuild the small mesh per (face, camera)
+    for (int face = 0; face < 6 && !rc; ++face) {
+      (void)hipMemsetAsync(acc.p, 0, nf * 16, c->stream);
+      for (int s = 0; s < c->S; ++s) {
+        if (!include[s]) {
+          continue;
+        }
+        hipLaunchKernelGGL(k_canopy_mesh, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), s,
+                           c->rephotoColor.as<uint16_t>() + (size_t)s * n * 3, c->rephotoDisp.as<float>() + (size_t)s * n, w,
+                           h, vert.as<float4>(), rgba.as<float4>());
+        (void)hipMemsetAsync(zbuf.p, 0, nf * 8, c->stream);
+        hipLaunchKernelGGL(k_canopy_raster, grid2d(w - 1, h - 1, 2, kBlk2d), kBlk2d, 0, c->stream, vert.as<float4>(),
+                           rgba.as<float4>(), w, h, cx, cy, cz, face, E, zbuf.as<unsigned long long>());
+        hipLaunchKernelGGL(k_canopy_resolve, grid2d(E, E, 1, kBlk2d), kBlk2d, 0, c->stream, vert.as<float4>(),
+                           rgba.as<float4>(), w, h, cx, cy, cz, face, E, zbuf.as<unsigned long long>(), acc.as<float4>());
+      }
+      hipLaunchKernelGGL(k_canopy_finish, grid2d(E, E, 1, kBlk2d), kBlk2d, 0, c->stream, acc.as<float4>(), face, E,
+                         out.as<float4>());
+      if (hipGetLastError() != hipSuccess) {
+        rc = fail(c, "HIP error launching the canopy kernels");
+      }
+    }
+    if (!rc && (hipStreamSynchronize(c->stream) != hipSuccess ||
+                hipMemcpy(out_bgra, out.p, nf * 6 * 16, hipMemcpyDeviceToHost) != hipSuccess)) {
+      rc = fail(c, "HIP error in derp_canopy_cubemap: %s", hipGetErrorString(hipGetLastError()));
+    }
+  }
+  for (DevBuf* b : {&vert, &rgba, &zbuf, &acc, &out}) {
+    b->release();
+  }
+  return rc;
+}
+
 int derp_download_mismatch_mask(derp_ctx* c, int d, uint8_t* out) {
   TRY(need_current(c, false));
   if (d < 0 || d >= c->D || !out) {

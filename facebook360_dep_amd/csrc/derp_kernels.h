@@ -1971,4 +1971,213 @@ __global__ void k_ssim_score(const float* __restrict__ muX, const float* __restr
   }
 }
 
+// ----------------------------------------------------------------------------------------
+// Rephotography renderer — CanopyScene::cubemap (source/render/CanopyScene.cpp:36-69,72-196,198-283,285-374,
+// 447-476) as ComputeRephotographyErrors.cpp:77-95 drives it, without OpenGL: per camera a vertex per
+// disparity pixel (camera.rig(pixel centre, 1 / disparity)), stripify()'s two triangles per pixel quad, depth
+// test GL_LEQUAL, fragment = bilinear colour sample (alpha = inside the image circle, discarded at 0) weighted
+// by the minor axis of the screen -> texture Jacobian and the cone; weight = exp(30 alpha) - 1, premultiplied
+// accumulation over the cameras, un-premultiply, NaN -> 0; six 90-degree faces stacked top to bottom.
+// Choices where OpenGL is implementation-defined: see DESIGN.md §8. fp32 like the shaders.
+//   k_canopy_mesh     vertex + RGBA per (camera, pixel)
+//   k_canopy_raster   one thread per triangle: 64-bit atomicMax of (1/z bits, triangle id) per covered pixel
+//   k_canopy_resolve  one thread per face pixel: winner's interpolants, derivatives, weight -> accumulate
+//   k_canopy_finish   un-premultiply into the stacked cubemap
+// ----------------------------------------------------------------------------------------
+struct CanopyTri {
+  float sx[3], sy[3], invd[3], tu[3], tv[3];
+  float area;
+};
+__constant__ int kCubeAxes[6][3][2] = {  // EXT_texture_cube_map: {major axis, sc, tc} x {axis index, sign}
+    {{0, +1}, {2, -1}, {1, -1}}, {{0, -1}, {2, +1}, {1, -1}}, {{1, +1}, {0, +1}, {2, +1}},
+    {{1, -1}, {0, +1}, {2, -1}}, {{2, +1}, {0, +1}, {1, -1}}, {{2, -1}, {0, -1}, {1, -1}}};
+
+__global__ void k_canopy_mesh(const Cam* __restrict__ cams, int s, const uint16_t* __restrict__ bgr,
+                              const float* __restrict__ disp, int W, int H, float4* __restrict__ vert,
+                              float4* __restrict__ rgba) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= W || y >= H) {
+    return;
+  }
+  const Cam& c = cams[s];
+  const size_t i = (size_t)y * W + x;
+  const double px = (x + 0.5) / (double)W, py = (y + 0.5) / (double)H;
+  const float distance = 1.0f / disp[i];  // disparityMesh, CanopyScene.cpp:453
+  const D3 dir = rig_direction(c, px, py, c.principal[0], c.principal[1], c.focal[0], c.focal[1]);
+  const double depth = (double)distance;
+  vert[i] = make_float4((float)(c.pos[0] + dir.x * depth), (float)(c.pos[1] + dir.y * depth),
+                        (float)(c.pos[2] + dir.z * depth), 0.0f);
+  const float a = outside_image_circle(c, px, py, c.principal[0], c.principal[1], c.focal[0], c.focal[1]) ? 0.0f : 1.0f;
+  rgba[i] = make_float4((float)bgr[3 * i] / 65535.0f, (float)bgr[3 * i + 1] / 65535.0f, (float)bgr[3 * i + 2] / 65535.0f, a);
+}
+
+__device__ __forceinline__ bool canopy_setup(const float4* __restrict__ vert, int W, int H, int qx, int qy, int t,
+                                             float cxp, float cyp, float czp, int face, int E, CanopyTri& T) {
+  const float scaleX = (float)(1.0 / (double)W), scaleY = (float)(1.0 / (double)H);  // Canopy::scale
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    // t = 0: A B C, t = 1: B C D with A = (x, y), B = (x, y+1), C = (x+1, y), D = (x+1, y+1)
+    const int ox = t == 0 ? (k == 2) : (k >= 1), oy = t == 0 ? (k == 1) : (k != 1);
+    const int vx = qx + ox, vy = qy + oy;
+    const float4 p = vert[(size_t)vy * W + vx];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) {
+      return false;
+    }
+    const float q[3] = {p.x - cxp, p.y - cyp, p.z - czp};
+    const float d = (float)kCubeAxes[face][0][1] * q[kCubeAxes[face][0][0]];
+    const float cx = (float)kCubeAxes[face][1][1] * q[kCubeAxes[face][1][0]];
+    const float cy = (float)kCubeAxes[face][2][1] * q[kCubeAxes[face][2][0]];
+    if (!(d >= 0.1f)) {  // kNearZ
+      return false;
+    }
+    T.sx[k] = (cx / d + 1.0f) * 0.5f * (float)E;
+    T.sy[k] = (cy / d + 1.0f) * 0.5f * (float)E;
+    T.invd[k] = 1.0f / d;
+    T.tu[k] = scaleX * ((float)vx + 0.5f);
+    T.tv[k] = scaleY * ((float)vy + 0.5f);
+  }
+  T.area = (T.sx[1] - T.sx[0]) * (T.sy[2] - T.sy[0]) - (T.sx[2] - T.sx[0]) * (T.sy[1] - T.sy[0]);
+  return T.area != 0.0f && isfinite(T.area);
+}
+__device__ __forceinline__ bool canopy_bary(const CanopyTri& T, float px, float py, float (&l)[3], bool test) {
+  const float e0 = (T.sx[2] - T.sx[1]) * (py - T.sy[1]) - (T.sy[2] - T.sy[1]) * (px - T.sx[1]);
+  const float e1 = (T.sx[0] - T.sx[2]) * (py - T.sy[2]) - (T.sy[0] - T.sy[2]) * (px - T.sx[2]);
+  const float e2 = (T.sx[1] - T.sx[0]) * (py - T.sy[0]) - (T.sy[1] - T.sy[0]) * (px - T.sx[0]);
+  l[0] = e0 / T.area;
+  l[1] = e1 / T.area;
+  l[2] = e2 / T.area;
+  return !test || (l[0] >= 0.0f && l[1] >= 0.0f && l[2] >= 0.0f);
+}
+__device__ __forceinline__ float canopy_invz(const CanopyTri& T, const float (&l)[3]) {
+  return l[0] * T.invd[0] + l[1] * T.invd[1] + l[2] * T.invd[2];
+}
+__device__ __forceinline__ void canopy_tex(const CanopyTri& T, float px, float py, float& u, float& v) {
+  float l[3];
+  canopy_bary(T, px, py, l, false);
+  const float iz = canopy_invz(T, l);
+  u = (l[0] * (T.tu[0] * T.invd[0]) + l[1] * (T.tu[1] * T.invd[1]) + l[2] * (T.tu[2] * T.invd[2])) / iz;
+  v = (l[0] * (T.tv[0] * T.invd[0]) + l[1] * (T.tv[1] * T.invd[1]) + l[2] * (T.tv[2] * T.invd[2])) / iz;
+}
+__device__ __forceinline__ float4 canopy_sample(const float4* __restrict__ rgba, int W, int H, float u, float v) {
+  const float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
+  const float x0f = floorf(fx), y0f = floorf(fy);
+  const float ax = fx - x0f, ay = fy - y0f;
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+  const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+  const float4 c00 = rgba[(size_t)ya * W + xa], c10 = rgba[(size_t)ya * W + xb];
+  const float4 c01 = rgba[(size_t)yb * W + xa], c11 = rgba[(size_t)yb * W + xb];
+  auto lerp2 = [&](float p00, float p10, float p01, float p11) {
+    const float top = p00 * (1.0f - ax) + p10 * ax, bot = p01 * (1.0f - ax) + p11 * ax;
+    return top * (1.0f - ay) + bot * ay;
+  };
+  return make_float4(lerp2(c00.x, c10.x, c01.x, c11.x), lerp2(c00.y, c10.y, c01.y, c11.y),
+                     lerp2(c00.z, c10.z, c01.z, c11.z), lerp2(c00.w, c10.w, c01.w, c11.w));
+}
+
+__global__ void k_canopy_raster(const float4* __restrict__ vert, const float4* __restrict__ rgba, int W, int H, float cx,
+                                float cy, float cz, int face, int E, unsigned long long* __restrict__ zbuf) {
+  const int qx = blockIdx.x * blockDim.x + threadIdx.x, qy = blockIdx.y * blockDim.y + threadIdx.y;
+  const int t = blockIdx.z;
+  if (qx + 1 >= W || qy + 1 >= H) {
+    return;
+  }
+  CanopyTri T;
+  if (!canopy_setup(vert, W, H, qx, qy, t, cx, cy, cz, face, E, T)) {
+    return;
+  }
+  const float minx = fminf(T.sx[0], fminf(T.sx[1], T.sx[2])), maxx = fmaxf(T.sx[0], fmaxf(T.sx[1], T.sx[2]));
+  const float miny = fminf(T.sy[0], fminf(T.sy[1], T.sy[2])), maxy = fmaxf(T.sy[0], fmaxf(T.sy[1], T.sy[2]));
+  if (!(maxx >= 0.0f && maxy >= 0.0f && minx <= (float)E && miny <= (float)E)) {
+    return;
+  }
+  const int i0 = max(0, (int)ceilf(minx - 0.5f)), i1 = min(E - 1, (int)floorf(maxx - 0.5f));
+  const int j0 = max(0, (int)ceilf(miny - 0.5f)), j1 = min(E - 1, (int)floorf(maxy - 0.5f));
+  const unsigned triId = (unsigned)(((size_t)qy * W + qx) * 2 + t);
+  for (int j = j0; j <= j1; ++j) {
+    for (int i = i0; i <= i1; ++i) {
+      float l[3];
+      if (!canopy_bary(T, i + 0.5f, j + 0.5f, l, true)) {
+        continue;
+      }
+      const float iz = canopy_invz(T, l);
+      if (!(iz > 0.0f)) {
+        continue;
+      }
+      float u, v;
+      canopy_tex(T, i + 0.5f, j + 0.5f, u, v);
+      if (canopy_sample(rgba, W, H, u, v).w == 0.0f) {
+        continue;  // discard: no colour, no depth
+      }
+      // nearer = larger 1/z; equal depth: the later triangle wins (GL_LEQUAL)
+      atomicMax(&zbuf[(size_t)j * E + i], ((unsigned long long)__float_as_uint(iz) << 32) | triId);
+    }
+  }
+}
+
+__global__ void k_canopy_resolve(const float4* __restrict__ vert, const float4* __restrict__ rgba, int W, int H, float cx,
+                                 float cy, float cz, int face, int E, const unsigned long long* __restrict__ zbuf,
+                                 float4* __restrict__ acc) {
+  __shared__ unsigned long long expTab[32];
+  {
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < 32) {
+      expTab[t] = kExp2fTab[t];
+    }
+  }
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= E || j >= E) {
+    return;
+  }
+  const unsigned long long key = zbuf[(size_t)j * E + i];
+  if (!key) {
+    return;
+  }
+  const unsigned triId = (unsigned)key;
+  const int t = triId & 1, q = triId >> 1, qx = q % W, qy = q / W;
+  CanopyTri T;
+  canopy_setup(vert, W, H, qx, qy, t, cx, cy, cz, face, E, T);
+  float u, v;
+  canopy_tex(T, i + 0.5f, j + 0.5f, u, v);
+  const float4 c = canopy_sample(rgba, W, H, u, v);
+  const int ib = i & ~1, jb = j & ~1;
+  float ua, va, ub, vb;
+  canopy_tex(T, ib + 0.5f, j + 0.5f, ua, va);
+  canopy_tex(T, ib + 1.5f, j + 0.5f, ub, vb);
+  const float ax = ub - ua, ay = vb - va;  // dFdx(texVar): fine derivative inside the 2x2 quad
+  canopy_tex(T, i + 0.5f, jb + 0.5f, ua, va);
+  canopy_tex(T, i + 0.5f, jb + 1.5f, ub, vb);
+  const float bx = ub - ua, by = vb - va;  // dFdy(texVar)
+  const float aa = ax * ax + ay * ay, bb = bx * bx + by * by, ab = ax * bx + ay * by;
+  const float hx = (aa - bb) / 2.0f;
+  const float minor = (aa + bb) / 2.0f - sqrtf(hx * hx + ab * ab);
+  float alpha = c.w * minor;
+  const float du = u - 0.5f, dv = v - 0.5f;
+  const float cone = fmaxf(1.0f / 255.0f, 1.0f - 2.0f * sqrtf(du * du + dv * dv));
+  alpha *= cone;
+  const float weight = expf_glibc(30.0f * alpha, expTab) - 1.0f;  // accumulateFS, kLogK = 30
+  float4 a = acc[(size_t)j * E + i];
+  a.x = weight * c.x + a.x;  // glBlendFuncSeparate(GL_SRC_ALPHA, GL_ONE, GL_ONE, GL_ONE)
+  a.y = weight * c.y + a.y;
+  a.z = weight * c.z + a.z;
+  a.w = weight + a.w;
+  acc[(size_t)j * E + i] = a;
+}
+
+// unpremulFS + zeroOutNans; GL row j (bottom-up) of face -> row face * E + (E - 1 - j) of the stacked cubemap
+__global__ void k_canopy_finish(const float4* __restrict__ acc, int face, int E, float4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y * blockDim.y + threadIdx.y;
+  if (i >= E || j >= E) {
+    return;
+  }
+  const float4 a = acc[(size_t)j * E + i];
+  float4 o = make_float4(a.x / a.w, a.y / a.w, a.z / a.w, a.w / a.w);
+  o.x = o.x != o.x ? 0.0f : o.x;
+  o.y = o.y != o.y ? 0.0f : o.y;
+  o.z = o.z != o.z ? 0.0f : o.z;
+  o.w = o.w != o.w ? 0.0f : o.w;
+  out[((size_t)face * E + (E - 1 - j)) * E + i] = o;
+}
+
 }  // namespace derp

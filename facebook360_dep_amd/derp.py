@@ -57,7 +57,7 @@ EXPORTS = [
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
     "derp_stage_ping_pong", "derp_stage_mismatches", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
-    "derp_ssim", "derp_average_score", "derp_rephotograph", "derp_rephotograph_upload", "derp_rephotograph_render",
+    "derp_ssim", "derp_average_score", "derp_rephotograph", "derp_rephotograph_upload", "derp_rephotograph_render", "derp_canopy_cubemap",
     "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
@@ -377,6 +377,23 @@ class Derp:
         dp = (C.c_void_p * len(disps))(*[d.ctypes.data for d in disps])
         out = np.zeros((h, w, 4), dtype=np.float32)
         self._ck(lib().derp_rephotograph(self.h, target, cp, dp, w, h, _p(out)))
+        return out
+
+    def rephotograph_upload(self, colors, disps):
+        colors = [np.ascontiguousarray(c, dtype=np.uint16) for c in colors]
+        disps = [np.ascontiguousarray(d, dtype=np.float32) for d in disps]
+        h, w = disps[0].shape
+        cp = (C.c_void_p * len(colors))(*[c.ctypes.data for c in colors])
+        dp = (C.c_void_p * len(disps))(*[d.ctypes.data for d in disps])
+        self._ck(lib().derp_rephotograph_upload(self.h, cp, dp, w, h))
+
+    def canopy_cubemap(self, include, centre, edge):
+        """CanopyScene::cubemap of the uploaded cameras with include[s] != 0, seen from `centre`
+        -> BGRA f32 [6 * edge, edge, 4]."""
+        inc = np.ascontiguousarray(include, dtype=np.uint8)
+        ctr = np.ascontiguousarray(centre, dtype=np.float64)
+        out = np.zeros((6 * edge, edge, 4), dtype=np.float32)
+        self._ck(lib().derp_canopy_cubemap(self.h, _p(inc), _p(ctr), edge, _p(out)))
         return out
 
     def fov_mask(self, d, w, h):

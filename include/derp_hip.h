@@ -193,6 +193,13 @@ int derp_rephotograph(derp_ctx* ctx, int target, const uint16_t* const* colors, 
 int derp_rephotograph_upload(derp_ctx* ctx, const uint16_t* const* colors, const float* const* disparities, int w,
                              int h);
 int derp_rephotograph_render(derp_ctx* ctx, int target, float* out_bgra);
+/* The reference's renderer for that score, without OpenGL: CanopyScene::cubemap
+ * (source/render/CanopyScene.cpp:198-374) of the cameras include[s] != 0 of the last
+ * derp_rephotograph_upload, seen from `centre` (rig space, 3 doubles) — disparity meshes, depth test, stretch /
+ * cone weights, soft-max accumulation, un-premultiply — as six edge x edge faces (+X -X +Y -Y +Z -Z) stacked
+ * top to bottom: out = BGRA float [6 * edge][edge][4], alpha in {0, 1}. generateCubemaps(removeOne(i)) =
+ * include everything but i; the reference side = include only i (ComputeRephotographyErrors.cpp:140-145). */
+int derp_canopy_cubemap(derp_ctx* ctx, const uint8_t* include, const double* centre, int edge, float* out_bgra);
 /* generateFovMasks for one destination camera at an arbitrary size (DerpUtil.cpp:259-276) */
 int derp_fov_mask(derp_ctx* ctx, int dst, int w, int h, uint8_t* out);
 /* upsampleDisparities for one camera (UpsampleDisparityLib.cpp:98-182). fg_mask / fg_mask_up /

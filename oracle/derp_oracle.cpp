@@ -29,6 +29,7 @@
 
 #include "oracle_camera.h"
 #include "oracle_cv.h"
+#include "oracle_canopy.h"
 
 namespace oracle {
 
@@ -1832,6 +1833,11 @@ void oracle_compute_ssim(
 void oracle_average_score(const float* score, const uint8_t* mask, int w, int h, double* out3) {
   const size_t n = (size_t)w * h;
   averageScore(std::vector<float>(score, score + n * 3), mask, n, out3);
+}
+// CanopyScene::cubemap (CanopyScene.cpp:198-374) of the cameras include[s] != 0 seen from `centre`
+void oracle_canopy_cubemap(const OracleRig* r, const uint16_t* const* colors, const float* const* disps, int w, int h,
+                           const uint8_t* include, const double* centre, int edge, float* outBgra) {
+  canopyCubemap(r->cams, colors, disps, w, h, include, centre, edge, outBgra);
 }
 void oracle_rephotograph(
     const OracleRig* r, int target, const uint16_t* const* colors, const float* const* disps, int w, int h, float* outBgra) {

@@ -420,6 +420,20 @@ def format_results(avg):
     return "R %.2f%%, G %.2f%%, B %.2f%%" % (100 * avg[2], 100 * avg[1], 100 * avg[0])
 
 
+def canopy_cubemap(rig, colors, disps, include, centre, edge):
+    """CanopyScene::cubemap of the cameras include[s] != 0 seen from `centre` -> BGRA f32 [6 * edge, edge, 4]."""
+    colors = [np.ascontiguousarray(c, dtype=np.uint16) for c in colors]
+    disps = [np.ascontiguousarray(d, dtype=np.float32) for d in disps]
+    h, w = disps[0].shape
+    cp = (C.c_void_p * len(colors))(*[c.ctypes.data for c in colors])
+    dp = (C.c_void_p * len(disps))(*[d.ctypes.data for d in disps])
+    inc = np.ascontiguousarray(include, dtype=np.uint8)
+    ctr = np.ascontiguousarray(centre, dtype=np.float64)
+    out = np.zeros((6 * edge, edge, 4), dtype=np.float32)
+    lib().oracle_canopy_cubemap(rig.h, cp, dp, w, h, _p(inc), _p(ctr), edge, _p(out))
+    return out
+
+
 def rephotograph(rig, target, colors, disps):
     """rig: normalised Rig; colors[j] u16 [h, w, 3]; disps[j] f32 [h, w] -> BGRA f32 [h, w, 4]."""
     colors = [np.ascontiguousarray(c, dtype=np.uint16) for c in colors]

@@ -931,6 +931,50 @@ def _mixed_type_rig(res):
     return {"cameras": cams}
 
 
+def test_canopy_cubemap(built):
+    """The rephotography renderer (CanopyScene::cubemap, CanopyScene.cpp:198-374, as
+    ComputeRephotographyErrors.cpp:77-95 drives it) against the oracle's restatement: the camera alone and
+    all the other cameras, seen from the camera, on analytic and on perturbed disparities (depth
+    discontinuities, a NaN hole, stretched triangles). Bit for bit, including the {0,1} alpha; then the MSSIM
+    of the pair through derp_ssim / derp_average_score."""
+    from facebook360_dep_amd import derp, synth
+    from oracle import oracle_lib as O
+
+    n, res = 6, 96
+    rig = synth.make_rig(n, res)
+    frame = synth.make_frame(rig, [(res, res)], device="cpu")
+    colors = frame["color"][0]
+    disps = [d.copy() for d in frame["truth"]]
+    rng = np.random.default_rng(3)
+    disps[1][20:40, 30:50] *= 2.5            # a foreground slab: long stretched triangles at its border
+    disps[3][60:64, 10:14] = np.nan          # a hole
+    disps[4] = disps[4] * (1 + 0.02 * rng.standard_normal(disps[4].shape)).astype(np.float32)
+    R = O.Rig(rig["cameras"]).normalize()
+    g = derp.Derp(rig["cameras"])
+    g.rephotograph_upload(colors, disps)
+    E = 64
+    for i in (0, 3):
+        centre = rig["cameras"][i]["origin"]
+        only = [int(s == i) for s in range(n)]
+        others = [int(s != i) for s in range(n)]
+        got_ref, got_ren = g.canopy_cubemap(only, centre, E), g.canopy_cubemap(others, centre, E)
+        want_ref = O.canopy_cubemap(R, colors, disps, only, centre, E)
+        want_ren = O.canopy_cubemap(R, colors, disps, others, centre, E)
+        assert got_ref.shape == (6 * E, E, 4)
+        assert _float_equal(got_ref, want_ref) == 0 and _float_equal(got_ren, want_ren) == 0, i
+        alpha = got_ref[..., 3]
+        assert set(np.unique(alpha)) <= {0.0, 1.0} and 0.3 < alpha.mean() < 0.7  # a 180-degree camera: half the sphere
+        assert (got_ren[..., 3] > 0).mean() > 0.95
+        mask = (alpha > 0).astype(np.uint8)
+        score = g.ssim(got_ref[..., :3], got_ren[..., :3], 1)
+        want = O.compute_ssim(want_ref[..., :3], want_ren[..., :3], 1)
+        assert _float_equal(score, want) == 0
+        avg = derp.average_score(score, mask)
+        print("camera %d MSSIM from its neighbours: %s" % (i, derp.format_results(avg)))
+        assert all(0.2 < v <= 1.0 for v in avg)
+    g.close()
+
+
 def test_camera_types(built):
     """RECTILINEAR, EQUISOLID and ORTHOGRAPHIC cameras (Camera.h:301-378) through the whole pyramid:
     warp tables (unproject + project), FOV masks and the cost loop's fp64 `sees` for every type."""
