@@ -467,17 +467,18 @@ int upsample_lanczos_dev(derp_ctx* c, const float* in, int sw, int sh, float* ou
   return 0;
 }
 
+// `planes` images (destination cameras) in one launch: every pointer addresses `planes` contiguous planes
 int upsample_masked_dev(derp_ctx* c, const float* in, const uint8_t* mask, int sw, int sh, const uint8_t* maskUp,
-                        const float* bgUp, float* out, int dw, int dh) {
+                        const float* bgUp, float* out, int dw, int dh, int planes = 1) {
   // getRadius (UpsampleDisparityLib.cpp:93-96): int(scale*scale + 1), float arithmetic
   const float scale = float(dw) / float(sw);
   const int radius = (int)(scale * scale + 1);
   TRY(ensure_spiral(c, radius));
-  ALLOC(c, c->lanczosTmp, (size_t)dw * dh * sizeof(float));
-  hipLaunchKernelGGL(k_upsample_nearest_masked, grid2d(dw, dh, 1, kBlk2d), kBlk2d, 0, c->stream, in, mask, sw, sh,
+  ALLOC(c, c->lanczosTmp, (size_t)dw * dh * planes * sizeof(float));
+  hipLaunchKernelGGL(k_upsample_nearest_masked, grid2d(dw, dh, planes, kBlk2d), kBlk2d, 0, c->stream, in, mask, sw, sh,
                      maskUp, dw, dh, c->lanczosTmp.as<float>());
   KCHECK(c);
-  hipLaunchKernelGGL(k_spiral_fill, grid2d(dw, dh, 1, kBlk2d), kBlk2d, 0, c->stream, c->lanczosTmp.as<float>(), bgUp,
+  hipLaunchKernelGGL(k_spiral_fill, grid2d(dw, dh, planes, kBlk2d), kBlk2d, 0, c->stream, c->lanczosTmp.as<float>(), bgUp,
                      maskUp, dw, dh, c->spiral.as<int2>(), c->spiralN, out);
   KCHECK(c);
   return 0;
@@ -765,33 +766,38 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
                          c->staging.as<uint8_t>(), c->pyrFg[level + 1].as<uint8_t>(), c->dst2src.as<int>(), 0,
                          (size_t)sw * sh, c->staging.as<uint8_t>());
       KCHECK(c);
-      for (int d = 0; d < c->D; ++d) {
-        TRY(upsample_masked_dev(c, c->pyrDisp[level + 1].as<float>() + (size_t)d * sw * sh,
-                                c->staging.as<uint8_t>() + (size_t)d * sw * sh, sw, sh,
-                                c->maskAnd.as<uint8_t>() + (size_t)d * n, c->pyrBg[level].as<float>() + (size_t)d * n,
-                                c->disparity.as<float>() + (size_t)d * n, W, H));
-      }
+      TRY(upsample_masked_dev(c, c->pyrDisp[level + 1].as<float>(), c->staging.as<uint8_t>(), sw, sh,
+                              c->maskAnd.as<uint8_t>(), c->pyrBg[level].as<float>(), c->disparity.as<float>(), W, H, c->D));
     }
   } else {
     HIPCHK(c, hipMemsetAsync(c->disparity.p, 0, n * c->D * sizeof(float), c->stream));
   }
-  // table budget -> dst batch
-  size_t freeB = 0, totalB = 0;
-  HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+  // table budget -> dst batch. When the buffers already hold every destination's tables of this level (the
+  // steady state of a sequence: same levels frame after frame) there is nothing to ask the runtime.
   const size_t per = table_bytes_per_dst(c, W, H);
-  size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes;
-  if (const char* e = getenv("DERP_TABLE_BUDGET_GB")) {
-    budget = std::min<size_t>(budget, (size_t)(atof(e) * (1ull << 30)));
-  } else {
-    budget = (size_t)(budget * 0.85);
-  }
-  int DB = (int)std::min<size_t>((size_t)c->D, budget / std::max<size_t>(per, 1));
-  if (DB < 1) {
-    return fail(c, "projection tables for one destination (%zu bytes) exceed the table budget (%zu bytes)", per, budget);
-  }
-  {  // equal-sized batches: 24 destinations under a 23-destination budget run as 12 + 12, not 23 + 1
-    const int batches = (c->D + DB - 1) / DB;
-    DB = (c->D + batches - 1) / batches;
+  int DB = c->D;
+  {
+    const size_t wpAll = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW) * (c->S - 1) * c->D * sizeof(float2);
+    const size_t cpAll = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC) * (c->S - 1) * c->D * sizeof(ushort4);
+    const bool resident = c->projWarp.bytes >= wpAll && c->projColor.bytes >= cpAll && c->projBias.bytes >= cpAll &&
+        !getenv("DERP_TABLE_BUDGET_GB");
+    if (!resident) {
+      size_t freeB = 0, totalB = 0;
+      HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
+      size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes;
+      if (const char* e = getenv("DERP_TABLE_BUDGET_GB")) {
+        budget = std::min<size_t>(budget, (size_t)(atof(e) * (1ull << 30)));
+      } else {
+        budget = (size_t)(budget * 0.85);
+      }
+      DB = (int)std::min<size_t>((size_t)c->D, budget / std::max<size_t>(per, 1));
+      if (DB < 1) {
+        return fail(c, "projection tables for one destination (%zu bytes) exceed the table budget (%zu bytes)", per, budget);
+      }
+      // equal-sized batches: 24 destinations under a 23-destination budget run as 12 + 12, not 23 + 1
+      const int batches = (c->D + DB - 1) / DB;
+      DB = (c->D + batches - 1) / batches;
+    }
   }
   c->DB = DB;
   const size_t wp = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW), cp = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC);

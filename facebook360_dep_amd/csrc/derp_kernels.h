@@ -1520,12 +1520,20 @@ __global__ void k_lanczos_v(const float* __restrict__ tmp, int SH, int DW, int D
 }
 
 // masked path, steps 1-3: coarse value outside (fov & fg) -> NaN, INTER_NEAREST, NaN outside maskUp
+// blockIdx.z = plane (destination camera): coarse planes are SW * SH apart, fine planes DW * DH
 __global__ void k_upsample_nearest_masked(const float* __restrict__ in, const uint8_t* __restrict__ mask, int SW,
                                           int SH, const uint8_t* __restrict__ maskUp, int DW, int DH,
                                           float* __restrict__ out) {
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= DW || y >= DH) {
     return;
+  }
+  {
+    const size_t ps = (size_t)blockIdx.z * SW * SH, pd = (size_t)blockIdx.z * DW * DH;
+    in += ps;
+    mask += ps;
+    maskUp += pd;
+    out += pd;
   }
   const double ifx = (double)SW / DW, ify = (double)SH / DH;
   const int sx = min((int)floor(x * ifx), SW - 1), sy = min((int)floor(y * ify), SH - 1);
@@ -1542,6 +1550,13 @@ __global__ void k_spiral_fill(const float* __restrict__ dispUp, const float* __r
   const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
   if (x >= W || y >= H) {
     return;
+  }
+  {
+    const size_t pd = (size_t)blockIdx.z * W * H;  // blockIdx.z = plane (destination camera)
+    dispUp += pd;
+    bgUp += pd;
+    maskUp += pd;
+    out += pd;
   }
   const size_t idx = (size_t)y * W + x;
   float v = dispUp[idx];
