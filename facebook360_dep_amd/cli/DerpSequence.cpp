@@ -14,6 +14,7 @@
 //
 // Multi-GPU: `--gpus N` forks one process per GPU of this node; or start the ranks yourself with
 // RANK / WORLD_SIZE / LOCAL_RANK in the environment (torchrun-style) and --rccl_id_file on a shared path.
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -82,12 +83,24 @@ int main(int argc, char** argv) {
       }
       kids.push_back(pid);
     }
-    if (!kids.empty()) {  // the parent only waits: any failing rank fails the job
-      int failed = 0;
-      for (pid_t k : kids) {
+    if (!kids.empty()) {  // the parent only waits: a failing rank fails the job and takes the others down with it
+      int failed = 0;        // (a rank that died would leave its peers blocked in the RCCL rendezvous / exchange)
+      size_t alive = kids.size();
+      while (alive > 0) {
         int st = 0;
-        waitpid(k, &st, 0);
-        failed += !(WIFEXITED(st) && WEXITSTATUS(st) == 0);
+        const pid_t done = waitpid(-1, &st, 0);
+        if (done < 0) {
+          break;
+        }
+        --alive;
+        if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
+          ++failed;
+          for (pid_t k : kids) {
+            if (k != done) {
+              kill(k, SIGTERM);  // harmless for ranks that already exited
+            }
+          }
+        }
       }
       fs::remove(idFile);
       if (failed) {

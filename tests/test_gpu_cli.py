@@ -204,6 +204,18 @@ def test_derp_sequence_cli_equals_the_three_binary_pipeline(dataset, tmp_path):
     assert not os.path.exists(os.path.join(out_c, "disparity_time_filtered_levels", "level_0", ids[1], "000001.pfm"))
 
 
+def test_derp_sequence_failing_rank_takes_the_job_down(dataset, tmp_path):
+    """--gpus 2 on a one-GPU box: rank 1 has no device. The parent must report the failure and stop rank 0
+    (which would otherwise wait in the RCCL rendezvous for ever) — non-zero exit, promptly."""
+    import time
+
+    t0 = time.time()
+    p = run("DerpSequence", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "o"), "--first=000000",
+            "--last=000002", "--partial_coverage", "--resolution=96", "--gpus=2", expect_ok=False)
+    assert p.returncode != 0 and "ranks failed" in p.stderr
+    assert time.time() - t0 < 120
+
+
 def test_output_format_exr_alone_is_refused(dataset, tmp_path):
     """PyramidLevel.h:515-516 writes .exr through OpenCV; this build has no EXR encoder and says so."""
     p = run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "o"), "--partial_coverage",
