@@ -50,6 +50,10 @@ def run():
     out["ssim_cam1"] = score
     out["ncc_cam1_r2"] = O.compute_ssim(x, rendered[..., :3], 2, 0, 0, 1)
     out["mssim_cam1"] = np.array(O.average_score(score, mask), dtype=np.float64)
+    # the rephotography renderer (CanopyScene::cubemap): camera 1 alone and all the others, seen from camera 1
+    centre = rig["cameras"][1]["origin"]
+    out["canopy_only_cam1"] = O.canopy_cubemap(R, cols, disps, [0, 1, 0, 0], centre, 32)
+    out["canopy_others_cam1"] = O.canopy_cubemap(R, cols, disps, [1, 0, 1, 1], centre, 32)
     frame1 = synth.make_frame(rig, sizes, frame=3, device="cpu")
     out["fgmask_cam0"] = O.generate_foreground_mask(cols[0], frame1["color"][0][0], 1, 0.04, 4)
     out["layers_cam0"] = O.layer_disparities(np.where(frame["masks"][0][0] == 1, disps[0], 0).astype(np.float32),

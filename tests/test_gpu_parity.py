@@ -115,6 +115,10 @@ def test_against_committed_golden_fixture(built):
     assert _float_equal(score, gold["ssim_cam1"]) == 0
     assert _float_equal(g.ssim(x, gold["rephoto_cam1"][..., :3], 2, 0, 0, 1), gold["ncc_cam1_r2"]) == 0
     assert derp.average_score(score, mask) == list(gold["mssim_cam1"])
+    g.rephotograph_upload(frame["color"][0], gd)
+    centre = rig["cameras"][1]["origin"]
+    assert _float_equal(g.canopy_cubemap([0, 1, 0, 0], centre, 32), gold["canopy_only_cam1"]) == 0
+    assert _float_equal(g.canopy_cubemap([1, 0, 1, 1], centre, 32), gold["canopy_others_cam1"]) == 0
     frame1 = synth.make_frame(rig, sizes, frame=3, device="cpu")
     assert np.array_equal(g.generate_foreground_mask(frame["color"][0][0], frame1["color"][0][0], 1, 0.04, 4),
                           gold["fgmask_cam0"])
