@@ -295,6 +295,8 @@ def main():
             "parallelism": "frames x%d" % world,
         },
         "per_gpu_value": round(value / world, 3),
+        # SURVEY 8(d), for completeness: every pyramid level's pixels, not only the finest level's
+        "pyramid_value": round(value * sum(w * h for (w, h) in sizes) / (w0 * h0), 3),
         "ms_per_frame": round(dt / args.steps / args.frames * 1e3 * world, 3),
         "roofline": roofline,
         "stage_ms_per_step": stage_ms,

@@ -204,6 +204,67 @@ def test_derp_sequence_cli_equals_the_three_binary_pipeline(dataset, tmp_path):
     assert not os.path.exists(os.path.join(out_c, "disparity_time_filtered_levels", "level_0", ids[1], "000001.pfm"))
 
 
+def test_derp_sequence_cli_masks_subset_and_resume(dataset, tmp_path):
+    """DerpSequence with foreground masks + temporal masking (pipeline.py:386), a --cameras subset, and a
+    resume from level 1 on disk (--level_start): against the oracle schedule."""
+    from facebook360_dep_amd import imageio as dio
+    from facebook360_dep_amd import sequence
+
+    root = dataset["root"]
+    n_levels = len(dataset["sizes"])
+    flags = ["--input_root=" + root, "--first=000000", "--last=000002", "--partial_coverage", "--resolution=96",
+             "--use_foreground_masks", "--do_temporal_masking", "--cameras=cam2,cam0"]
+    out = str(tmp_path / "o")
+    run("DerpSequence", *flags, "--output_root=" + out, "--level_end=1")           # levels 2, 1
+    run("DerpSequence", *flags, "--output_root=" + out, "--level_start=0")         # resumes from level 1 on disk
+
+    class Seq(common.OracleSequence):  # destinations = the subset, sources = the whole rig
+        def compute(self, level):
+            for t in self.owned:
+                prev = None
+                if level + 1 < len(self.sizes):
+                    prev = [self.disp[t][level + 1][d].numpy() for d in range(self.nd)]
+                L = common.oracle_level(self.rig, self.sizes, self.frames[t], level, self.res, self.res, prev,
+                                        dst_ids=["cam2", "cam0"], partial_coverage=True, threads=-1,
+                                        use_foreground_masks=True)
+                L.process()
+                for d in range(self.nd):
+                    self.disp[t][level][d] = __import__("torch").from_numpy(L.get_dst(d)[0])
+                self.fov[level] = np.stack([L.fov_mask(d) for d in range(self.nd)])
+
+    ref = Seq(dataset["rig"], dataset["sizes"], dataset["res"], 0, 2, threads=-1, use_foreground_masks=True,
+              frames={f: dataset["frames"][f] for f in range(3)})
+    ref.nd = 2
+    src_of = [2, 0]
+
+    def filt(level):  # the temporal stage on the destination subset: guides / fg masks of the matching source cameras
+        import torch
+        from oracle import oracle_lib as O
+        outp = {}
+        for t in ref.owned:
+            lo, hi = sequence.temporal_window(t, 0, 2, 2)
+            res = []
+            for d in range(2):
+                s = src_of[d]
+                masks = [ref.fov[level][d] & ref.fg[u][level][s].numpy() for u in range(lo, hi + 1)]
+                res.append(O.temporal_filter([ref.color[u][level][s].numpy() for u in range(lo, hi + 1)],
+                                             [ref.disp[u][level][d].numpy() for u in range(lo, hi + 1)], masks, t - lo,
+                                             0.01, O.temporal_space_radius(level), 0.5, 1.0, 0.5, threads=-1))
+            outp[t] = torch.from_numpy(np.stack(res))
+        for t in ref.owned:
+            ref.disp[t][level][:2].copy_(outp[t])
+
+    ref.filter = filt
+    sequence.run_schedule(ref, list(range(n_levels - 1, -1, -1)), 0, 2, 0, 1)
+    for level in range(n_levels):
+        for d, cam in enumerate(["cam2", "cam0"]):
+            for f in range(3):
+                got = dio.read_pfm(os.path.join(out, "disparity_levels", "level_%d" % level, cam, "%06d.pfm" % f))
+                want = ref.disp[f][level][d].numpy()
+                assert common.compare_disparity(got, want, 1e-4)[0] == 0, (level, cam, f)
+    assert sorted(os.listdir(os.path.join(out, "disparity_levels", "level_0"))) == ["cam0", "cam2"]
+
+
 def test_derp_sequence_failing_rank_takes_the_job_down(dataset, tmp_path):
     """--gpus 2 on a one-GPU box: rank 1 has no device. The parent must report the failure and stop rank 0
     (which would otherwise wait in the RCCL rendezvous for ever) — non-zero exit, promptly."""
