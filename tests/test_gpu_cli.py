@@ -232,8 +232,9 @@ def test_derp_sequence_cli_masks_subset_and_resume(dataset, tmp_path):
                     self.disp[t][level][d] = __import__("torch").from_numpy(L.get_dst(d)[0])
                 self.fov[level] = np.stack([L.fov_mask(d) for d in range(self.nd)])
 
-    ref = Seq(dataset["rig"], dataset["sizes"], dataset["res"], 0, 2, threads=-1, use_foreground_masks=True,
-              frames={f: dataset["frames"][f] for f in range(3)})
+    # one static background (--background_frame=000000) serves every frame, as synth.write_dataset lays it out
+    frames = {f: dict(dataset["frames"][f], bg_disp=dataset["frames"][0]["bg_disp"]) for f in range(3)}
+    ref = Seq(dataset["rig"], dataset["sizes"], dataset["res"], 0, 2, threads=-1, use_foreground_masks=True, frames=frames)
     ref.nd = 2
     src_of = [2, 0]
 
