@@ -121,6 +121,30 @@ def test_sequence_ranks_on_one_gpu_loopback(built, world, partition):
         g.close()
 
 
+def test_sequence_eight_frames_one_per_rank(built):
+    """The bench's N = 8 shape in miniature: 8 frames, 8 ranks (one frame each, <= 4 halo frames per rank),
+    emulated on one GPU — against the oracle and against the 1-rank run of the same sequence."""
+    from facebook360_dep_amd import sequence
+
+    n, res, rig, sizes = _setup("tiny")
+    first, last, world = 0, 7, 8
+    made = [_gpu_runner(rig, sizes, res, first, last, rank, world) for rank in range(world)]
+    runners = [r for (_, r) in made]
+    assert [r.owned for r in runners] == [[t] for t in range(8)]
+    assert runners[0].halo == [1, 2] and runners[3].halo == [1, 2, 4, 5] and runners[7].halo == [5, 6]
+    sequence.run_loopback(runners, len(sizes) - 1)
+    ref = _oracle_sequence("tiny", first, last)
+    assert _compare_with_oracle(runners, ref, n, sizes) == 0
+    g1, r1 = _gpu_runner(rig, sizes, res, first, last)
+    r1.run()
+    for t in range(8):
+        for d in range(n):
+            assert _bad(runners[t].download_disparity(t, 0, d), r1.download_disparity(t, 0, d)) == 0
+    g1.close()
+    for (g, r) in made:
+        g.close()
+
+
 def test_sequence_sixteen_cameras_against_oracle(built):
     """Config 3's rig (16 cameras) at 128^2, 3 frames split over 2 emulated ranks."""
     from facebook360_dep_amd import sequence, synth
