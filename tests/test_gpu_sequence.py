@@ -121,6 +121,38 @@ def test_sequence_ranks_on_one_gpu_loopback(built, world, partition):
         g.close()
 
 
+def test_sequence_edge_cases(built):
+    """More ranks than frames (a rank that owns nothing takes part in every phase and moves no data), a
+    one-frame sequence (window = the frame itself: the filter still runs, on one frame), time_radius 0."""
+    from facebook360_dep_amd import sequence
+
+    n, res, rig, sizes = _setup("tiny")
+    made = [_gpu_runner(rig, sizes, res, 0, 1, rank, 3) for rank in range(3)]
+    runners = [r for (_, r) in made]
+    assert [r.owned for r in runners] == [[0], [1], []] and runners[2].halo == []
+    sequence.run_loopback(runners, len(sizes) - 1)
+    ref = _oracle_sequence("tiny", 0, 1)
+    assert _compare_with_oracle(runners, ref, n, sizes) == 0
+    assert runners[2].stats()["bytes_received"] == 0
+    for (g, r) in made:
+        g.close()
+    # one frame: temporalJointBilateralFilter over a single frame is still a 3x3 spatial filter
+    g, r = _gpu_runner(rig, sizes, res, 3, 3)
+    r.run()
+    one = common.OracleSequence(rig, sizes, res, 3, 3, threads=-1)
+    sequence.run_schedule(one, list(range(len(sizes) - 1, -1, -1)), 3, 3, 0, 1)
+    assert _compare_with_oracle([r], one, n, sizes) == 0
+    assert _bad(one.raw[(3, 0)][0], one.disp[3][0][0].numpy()) > 0
+    g.close()
+    # time_radius 0 on two frames: no halo, each frame filtered on its own
+    g, r = _gpu_runner(rig, sizes, res, 0, 1, time_radius=0)
+    r.run()
+    zero = common.OracleSequence(rig, sizes, res, 0, 1, radius=0, threads=-1)
+    sequence.run_schedule(zero, list(range(len(sizes) - 1, -1, -1)), 0, 1, 0, 1, radius=0)
+    assert _compare_with_oracle([r], zero, n, sizes) == 0
+    g.close()
+
+
 def test_sequence_eight_frames_one_per_rank(built):
     """The bench's N = 8 shape in miniature: 8 frames, 8 ranks (one frame each, <= 4 halo frames per rank),
     emulated on one GPU — against the oracle and against the 1-rank run of the same sequence."""
