@@ -205,10 +205,79 @@ int seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, size_t* 
     }                                                                                            \
   } while (0)
 
+// this rank's sends and receives of one exchange over RCCL: one group on the context's stream
+int seq_exchange_rccl(derp_seq* q, int level, int kind) {
+  derp_ctx* c = q->c;
+  RcclApi* api = rccl_api();
+  NCCLCHK(c, api, api->GroupStart());
+  int rc = 0;
+  for (const derp_seq_transfer& tr : q->plan) {
+    void* p;
+    size_t bytes;
+    ncclResult_t r = ncclSuccess;
+    if (tr.from_rank == q->rank) {
+      rc = seq_buffer(q, tr.frame, level, kind, &p, &bytes);
+      if (!rc) {
+        r = api->Send(p, bytes, ncclUint8, tr.to_rank, q->comm, c->stream);
+        q->bytesSent += bytes;
+      }
+    } else if (tr.to_rank == q->rank) {
+      rc = seq_buffer(q, tr.frame, level, kind, &p, &bytes);
+      if (!rc) {
+        r = api->Recv(p, bytes, ncclUint8, tr.from_rank, q->comm, c->stream);
+        q->bytesRecv += bytes;
+      }
+    }
+    if (!rc && r != ncclSuccess) {
+      rc = fail(c, "RCCL error %s moving frame %d (%d -> %d)", api->GetErrorString(r), tr.frame, tr.from_rank, tr.to_rank);
+    }
+    if (rc) {
+      break;
+    }
+  }
+  const ncclResult_t e = api->GroupEnd();  // always closed, also on the error path
+  if (!rc && e != ncclSuccess) {
+    rc = fail(c, "RCCL error %s at ncclGroupEnd", api->GetErrorString(e));
+  }
+  return rc;
+}
+
+// loopback: pull from the peer contexts of this process
+int seq_exchange_loopback(derp_seq* q, int level, int kind) {
+  derp_ctx* c = q->c;
+  std::vector<char> synced(q->world, 0);
+  for (const derp_seq_transfer& tr : q->plan) {
+    if (tr.from_rank == q->rank) {
+      void* p;
+      size_t bytes;
+      TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
+      q->bytesSent += bytes;
+    }
+    if (tr.to_rank != q->rank) {
+      continue;
+    }
+    derp_seq* peer = q->peers[tr.from_rank];
+    if (!synced[tr.from_rank]) {
+      HIPCHK(c, hipStreamSynchronize(peer->c->stream));
+      synced[tr.from_rank] = 1;
+    }
+    void *src, *dst;
+    size_t bs, bd;
+    if (seq_buffer(peer, tr.frame, level, kind, &src, &bs)) {
+      return fail(c, "loopback peer %d: %s", tr.from_rank, peer->c->err.c_str());
+    }
+    TRY(seq_buffer(q, tr.frame, level, kind, &dst, &bd));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bd, hipMemcpyDeviceToDevice, c->stream));
+    q->bytesRecv += bd;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // pulls are complete before any peer overwrites its level
+  return 0;
+}
+
 // move buffers of `kind` at `level` along the plan (this rank's sends and receives)
 int seq_exchange(derp_seq* q, int level, int kind) {
   derp_ctx* c = q->c;
-  if (q->world == 1 || q->transport == SEQ_EXTERNAL) {
+  if (q->plan.empty() || q->transport == SEQ_EXTERNAL) {
     return 0;
   }
   if (q->transport == SEQ_NONE) {
@@ -216,56 +285,15 @@ int seq_exchange(derp_seq* q, int level, int kind) {
   }
   hipEvent_t ea = nullptr, eb = nullptr;
   HIPCHK(c, hipEventCreate(&ea));
-  HIPCHK(c, hipEventCreate(&eb));
-  HIPCHK(c, hipEventRecord(ea, c->stream));
-  if (q->transport == SEQ_RCCL) {
-    RcclApi* api = rccl_api();
-    NCCLCHK(c, api, api->GroupStart());
-    for (const derp_seq_transfer& tr : q->plan) {
-      void* p;
-      size_t bytes;
-      if (tr.from_rank == q->rank) {
-        TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
-        NCCLCHK(c, api, api->Send(p, bytes, ncclUint8, tr.to_rank, q->comm, c->stream));
-        q->bytesSent += bytes;
-      } else if (tr.to_rank == q->rank) {
-        TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
-        NCCLCHK(c, api, api->Recv(p, bytes, ncclUint8, tr.from_rank, q->comm, c->stream));
-        q->bytesRecv += bytes;
-      }
-    }
-    NCCLCHK(c, api, api->GroupEnd());
-  } else {  // loopback: pull from the peer contexts of this process
-    std::vector<char> synced(q->world, 0);
-    for (const derp_seq_transfer& tr : q->plan) {
-      if (tr.from_rank == q->rank) {
-        void* p;
-        size_t bytes;
-        TRY(seq_buffer(q, tr.frame, level, kind, &p, &bytes));
-        q->bytesSent += bytes;
-      }
-      if (tr.to_rank != q->rank) {
-        continue;
-      }
-      derp_seq* peer = q->peers[tr.from_rank];
-      if (!synced[tr.from_rank]) {
-        HIPCHK(c, hipStreamSynchronize(peer->c->stream));
-        synced[tr.from_rank] = 1;
-      }
-      void *src, *dst;
-      size_t bs, bd;
-      if (seq_buffer(peer, tr.frame, level, kind, &src, &bs)) {
-        return fail(c, "loopback peer %d: %s", tr.from_rank, peer->c->err.c_str());
-      }
-      TRY(seq_buffer(q, tr.frame, level, kind, &dst, &bd));
-      HIPCHK(c, hipMemcpyAsync(dst, src, bd, hipMemcpyDeviceToDevice, c->stream));
-      q->bytesRecv += bd;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // pulls are complete before any peer overwrites its level
+  if (hipEventCreate(&eb) != hipSuccess) {
+    (void)hipEventDestroy(ea);
+    return fail(c, "hipEventCreate failed");
   }
-  HIPCHK(c, hipEventRecord(eb, c->stream));
-  q->exchangeSpans.push_back({ea, eb});
-  return 0;
+  (void)hipEventRecord(ea, c->stream);
+  const int rc = q->transport == SEQ_RCCL ? seq_exchange_rccl(q, level, kind) : seq_exchange_loopback(q, level, kind);
+  (void)hipEventRecord(eb, c->stream);
+  q->exchangeSpans.push_back({ea, eb});  // drained (and destroyed) by derp_seq_stats / derp_seq_destroy
+  return rc;
 }
 
 void seq_drain_spans(derp_seq* q) {
