@@ -80,7 +80,7 @@ def test_derp_cli_resume_and_camera_subset(dataset, tmp_path):
 
     out = str(tmp_path / "out")
     common_flags = ["--input_root=" + dataset["root"], "--output_root=" + out, "--partial_coverage", "--resolution=96",
-                    "--cameras=cam2,cam0"]
+                    "--cameras=cam2,cam0", "--threads=0"]  # 0 = no I/O workers: decode and writes run inline
     run("DerpCLI", *common_flags, "--level_start=2", "--level_end=1")
     assert not os.path.exists(os.path.join(out, "disparity_levels", "level_0"))
     run("DerpCLI", *common_flags, "--level_start=0", "--level_end=0")
