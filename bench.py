@@ -261,6 +261,19 @@ def main():
         },
         "whole_step_algorithmic_GBps": round(b_alg(cnt["n_cost"], cnt["n_pair"]) / dt / 1e9, 1),
     }
+    # measured HBM bytes of a whole step (all kernels; the committed PMC passes ran the default
+    # sequence on one GPU, so only quoted for that shape) beside the compulsory floor: every source level read
+    # once per destination + disparity / masks read and written once
+    whole_fetch, whole_write = prof.get("whole_step_hbm_fetch_bytes"), prof.get("whole_step_hbm_write_bytes")
+    px_all = sum(w * h for (w, h) in sizes)
+    floor_bytes = args.frames * px_all * (n_cams * (n_cams - 1) * 8 + n_cams * (4 + 4 + 1 + 1))
+    if whole_fetch and world == 1 and args.frames == 8:
+        step_s = dt / args.steps
+        roofline["whole_step_hbm"] = {
+            "fetch_bytes": whole_fetch, "write_bytes": whole_write,
+            "GBps": round((whole_fetch + whole_write) / step_s / 1e9, 1),
+            "frac_of_peak": round((whole_fetch + whole_write) / step_s / 1e9 / HBM_PEAK_GBS, 4),
+            "compulsory_floor_bytes": floor_bytes}
 
     frames_here = len(runner.owned)
     out = {

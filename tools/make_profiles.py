@@ -103,6 +103,9 @@ entry = {
                                  ("k_ping_pong(", "k_random_proposals", "k_reproject", "k_proj_warp",
                                   "k_joint_bilateral", "k_blur3_u16", "k_masked_median", "k_brute_costs", "k_temporal")},
 }
+# every derp:: kernel of the PMC run (`bench.py --steps 1`: one step = the whole sequence)
+entry["whole_step_hbm_fetch_bytes"] = 2.0 * 1024.0 * sum(v["FETCH_SIZE"]["sum"] for v in pm.get("FETCH_SIZE", {}).values())
+entry["whole_step_hbm_write_bytes"] = 1024.0 * sum(v["WRITE_SIZE"]["sum"] for v in pm.get("WRITE_SIZE", {}).values())
 # effective clock of the profiled level-0 launch: GRBM cycles / its duration in the kernel trace (max duration row)
 for r in keep:
     if "k_ping_pong(" in r[0] and pp.get("chip_busy_cycles_per_launch"):
