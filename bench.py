@@ -266,7 +266,7 @@ def main():
     # once per destination + disparity / masks read and written once
     whole_fetch, whole_write = prof.get("whole_step_hbm_fetch_bytes"), prof.get("whole_step_hbm_write_bytes")
     px_all = sum(w * h for (w, h) in sizes)
-    floor_bytes = args.frames * px_all * (n_cams * (n_cams - 1) * 8 + n_cams * (4 + 4 + 1 + 1))
+    floor_bytes = args.frames * px_all * (n_cams * n_cams * 6 + n_cams * (4 + 4 + 1 + 1))
     if whole_fetch and world == 1 and args.frames == 8:
         step_s = dt / args.steps
         roofline["whole_step_hbm"] = {
