@@ -246,7 +246,6 @@ def main():
                  "%d SIMDs x %.1f GHz. The kernel gathers from L1/L2-resident tables: HBM is not its bound "
                  "(hbm_frac below), VALU issue is." % (N_SIMD, PEAK_CLOCK_GHZ)),
         "valu_busy_frac_at_measured_clock": prof.get("ping_pong_level0_valu_busy_frac"),
-        "profiled_effective_clock_ghz": prof.get("ping_pong_level0_effective_clock_ghz"),
         "wave_issue_breakdown": prof.get("ping_pong_level0_wave_cycle_shares"),
         "hbm_traffic_GBps": round(traffic / kernel_s / 1e9, 1) if traffic and kernel_s > 0 else None,
         "hbm_frac": round(traffic / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_s > 0 else None,
@@ -295,7 +294,8 @@ def main():
                          % (n_cams, res, res, args.frames, n_levels,
                             "per-level temporal filter (+-2 frames)" if temporal else "no temporal filter",
                             args.partition, frames_here)),
-            "name": args.config,
+            "name": "cfg3" if (args.config == "cfg2" and args.frames == 8 and temporal) else args.config,
+            "rig": args.config,
             "cameras": n_cams,
             "resolution": [res, res],
             "levels": [list(s) for s in sizes],
