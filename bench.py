@@ -109,6 +109,7 @@ def cpu_baseline(rig, sizes, frame, res, n_cams):
 
 def main():
     args = parse()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL peer-memory handles need it here
     import numpy as np  # noqa: F401
     import torch
 

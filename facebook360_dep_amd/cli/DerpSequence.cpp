@@ -59,6 +59,8 @@ int main(int argc, char** argv) {
   F.str("rccl_id_file", "", "file through which rank 0 hands the RCCL unique id to the other ranks [extension]");
   F.parse(argc, argv);
   Timer total;
+  // RCCL's peer-memory handles need the dmabuf IPC mode on this driver stack; keep the caller's choice if any
+  setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
 
   // ---- ranks: --gpus forks them; otherwise RANK / WORLD_SIZE / LOCAL_RANK from the environment
   int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), localRank = env_int("LOCAL_RANK", -1);
