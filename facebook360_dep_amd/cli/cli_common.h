@@ -836,7 +836,7 @@ struct IoPool {
   bool stop = false;
   explicit IoPool(int threads) {
     int n = threads < 0 ? (int)std::thread::hardware_concurrency() : threads;
-    n = std::min(n, 256);
+    n = std::min(n, 64);
     for (int i = 0; i < n; ++i) {
       workers.emplace_back([this] {
         for (;;) {
