@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=8, help="frames of the sequence (BASELINE config 3: 8)")
     ap.add_argument("--temporal", type=int, default=1, help="0 = no temporal filter (frames are then independent replicas)")
     ap.add_argument("--partition", default="block", choices=["block", "cyclic"])
+    ap.add_argument("--synth-device", default="cuda",
+                    help="where the synthetic frames are rendered: cuda (default, fast) | cpu (bit-identical to the frames "
+                         "the CPU tests render, so result_crc can be compared with the oracle's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the config-2 single-frame leg at N = 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
@@ -147,7 +150,7 @@ def main():
     runner = sequence.SequenceRunner(g, first, last, rank, world, do_temporal_filter=int(temporal), partition=partition)
     upload_s, frame0 = 0.0, None
     for t in runner.owned:  # every rank renders and uploads only the frames it owns
-        frame = synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cuda")
+        frame = synth.make_frame(rig, sizes, frame=t, seed=360 + t, device=args.synth_device)
         t0 = time.time()
         runner.upload_frame(t, frame)
         upload_s += time.time() - t0
@@ -204,6 +207,16 @@ def main():
     level_ms = [round(sum(g.profile_query(s, lv)["ms"] for s in derp.STAGES) / args.steps / max(len(runner.owned), 1), 3)
                 for lv in range(n_levels)]
     cnt = g.counters()
+    # ---- what was computed: CRC-32 of every frame's level-0 (filtered) disparity, gathered to rank 0, so that an
+    # N-GPU line can be checked against the 1-GPU line (tests/golden/bench_result_crc.json holds the N = 1 values)
+    crc = {str(t): "%08x" % v for t, v in runner.result_crc().items()}
+    transports = [transport]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (crc, transport))
+        crc = {k: v for (c, _) in gathered for k, v in c.items()}
+        transports = [t for (_, t) in gathered]
+    crc = {k: crc[k] for k in sorted(crc, key=int)}
     xs = runner.stats()
     exch = {"bytes_received_per_step": xs["bytes_received"] // max(args.steps, 1),
             "bytes_sent_per_step": xs["bytes_sent"] // max(args.steps, 1),
@@ -315,6 +328,10 @@ def main():
         "roofline": roofline,
         "stage_ms_per_step": stage_ms,
         "level_ms_per_frame": level_ms,  # all stages of one level of one frame (this rank), finest level first
+        # CRC-32 (zlib) of each frame's level-0 disparity after the last step, all destinations in rig order, raw
+        # float32 bytes: identical for every --gpus N and --partition if the sharded run computed the same depth maps
+        "result_crc": crc,
+        "halo_transport_per_rank": transports,
         "input_upload": {"bytes": upload_bytes, "seconds": round(upload_s, 3),
                          "note": "host->HBM staging of this rank's colour pyramids, outside the timed region"},
         "device": g.device_name(),

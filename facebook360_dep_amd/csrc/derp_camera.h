@@ -76,10 +76,68 @@ DERP_HD double undistort(const Cam& c, const double y) {
   return x0;
 }
 
-// Camera.h:301-341
+#if defined(__HIP_DEVICE_COMPILE__)
+// IEEE fp64 division for operands whose quotient neither overflows nor underflows: the reciprocal-refinement
+// sequence the compiler emits for `/` (two Newton steps, quotient, one correction) without its exponent
+// pre-scaling and special-case fix-up — the same roundings, so the same correctly rounded quotient.
+__device__ __forceinline__ double div_plain(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double q = n * r;
+  return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
+// atan2(y, x) for y >= 0 (the FTHETA projection: y = |xy|, x = -z), result in [0, pi]. fdlibm's atan
+// (s_atan.c: breakpoints 7/16, 11/16, 19/16, 39/16, the 11-term polynomial aT[], atanhi / atanlo) with the
+// argument reduction written on the pair (y, x) — (y - c x) / (x + c y) instead of (t - c) / (1 + c t) — so
+// that it takes ONE division; <= 1 ulp from glibc's atan2 (test_lean_atan2_against_libm compares 4 x 10^6
+// arguments through derp_debug_atan2_ypos), like the device library's routine it replaces in the cost kernels,
+// at less than half its instruction count.
+__device__ __forceinline__ double atan2_ypos(double y, double x) {
+  const double ax = fabs(x);
+  const bool c0 = y < 0.4375 * ax, c1 = y < 0.6875 * ax, c2 = y < 1.1875 * ax, c3 = y < 2.4375 * ax;
+  const double c = c1 ? 0.5 : c2 ? 1.0 : 1.5;
+  double num = __builtin_fma(-c, ax, y), den = __builtin_fma(c, y, ax);
+  num = c0 ? y : c3 ? num : -ax;
+  den = c0 ? ax : c3 ? den : y;
+  const double hi = c0 ? 0.0 : c1 ? 4.63647609000806093515e-01 : c2 ? 7.85398163397448278999e-01
+                     : c3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00;
+  const double lo = c0 ? 0.0 : c1 ? 2.26987774529616870924e-17 : c2 ? 3.06161699786838301793e-17
+                     : c3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17;
+  const double t = div_plain(num, den);
+  const double z = t * t, w = z * z;
+  double s1 = __builtin_fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
+  s1 = __builtin_fma(w, s1, 6.66107313738753120669e-02);
+  s1 = __builtin_fma(w, s1, 9.09088713343650656196e-02);
+  s1 = __builtin_fma(w, s1, 1.42857142725034663711e-01);
+  s1 = __builtin_fma(w, s1, 3.33333333333329318027e-01);
+  s1 = z * s1;
+  double s2 = __builtin_fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
+  s2 = __builtin_fma(w, s2, -7.69187620504482999495e-02);
+  s2 = __builtin_fma(w, s2, -1.11111104054623557880e-01);
+  s2 = __builtin_fma(w, s2, -1.99999999998764832476e-01);
+  s2 = w * s2;
+  double r = hi - ((t * (s1 + s2) - lo) - t);
+  if (x < 0) {
+    r = 3.1415926535897931160E+00 - (r - 1.2246467991473531772E-16);
+  }
+  return r;
+}
+#endif
+
+// Camera.h:301-341. LEAN (device, cost kernels only): fp64 atan2 / division through the routines above.
+template <bool LEAN = false>
 DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p) {
   if (c.type == DERP_FTHETA) {
     const double xy = sqrt(p.x * p.x + p.y * p.y);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (LEAN) {
+      const double r = atan2_ypos(xy, -p.z);
+      const double s = div_plain(distort(c, r), xy);
+      return {s * p.x, s * p.y};
+    }
+#endif
     const double r = atan2(xy, -p.z);
     const double s = distort(c, r) / xy;
     return {s * p.x, s * p.y};
@@ -159,6 +217,7 @@ DERP_HD bool outside_image_circle(const Cam& c, double px, double py, double prx
 
 // Camera.h:184-190 (+154-164, 121-128, 180-182). Returns false if the point is outside the
 // FOV cone or projects off the sensor; pix in units of (principal, focal, res).
+template <bool LEAN = false>
 DERP_HD bool sees(const Cam& c, const D3& rig, double prx, double pry, double fx, double fy,
                   double resx, double resy, D2& pix) {
   const D3 v = {rig.x - c.pos[0], rig.y - c.pos[1], rig.z - c.pos[2]};
@@ -183,7 +242,7 @@ DERP_HD bool sees(const Cam& c, const D3& rig, double prx, double pry, double fx
       sum3(c.R[0] * v.x, c.R[1] * v.y, c.R[2] * v.z),
       sum3(c.R[3] * v.x, c.R[4] * v.y, c.R[5] * v.z),
       back};
-  const D2 s = camera_to_sensor(c, cam);
+  const D2 s = camera_to_sensor<LEAN>(c, cam);
   pix.x = fx * s.x + prx;
   pix.y = fy * s.y + pry;
   return !(0 > pix.x || pix.x >= resx || 0 > pix.y || pix.y >= resy);

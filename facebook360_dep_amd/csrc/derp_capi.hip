@@ -1405,6 +1405,21 @@ int derp_cost_map(derp_ctx* c, int d, const float* disp, float* cost, float* con
   return 0;
 }
 
+int derp_debug_atan2_ypos(derp_ctx* c, const double* y, const double* x, double* out, size_t n) {
+  if (!c || !y || !x || !out) {
+    return fail(c, "bad arguments");
+  }
+  ALLOC(c, c->staging, 3 * n * sizeof(double));
+  double* d = c->staging.as<double>();
+  HIPCHK(c, hipMemcpyAsync(d, y, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d + n, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_debug_atan2_ypos, dim3(flat_grid(n)), dim3(256), 0, c->stream, d, d + n, d + 2 * n, n);
+  KCHECK(c);
+  HIPCHK(c, hipMemcpyAsync(out, d + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 int derp_debug_download(derp_ctx* c, int d, int s, int which, void* out) {
   TRY(need_current(c, false));
   const int L = c->cur;

@@ -26,14 +26,25 @@
 
 namespace derp {
 
+// waves per SIMD the register allocator must leave room for (__launch_bounds__): the cost kernels with coherent
+// gathers (ping-pong, brute force, cost map) run three (<= 168 VGPRs), random proposals two — its gathers miss L2
+// and a third wave only widens the working set (measured: 48.8 / 51.7 / 55.3 ms per frame at 2 / 3 / 4 waves)
 #ifndef DERP_COST_MIN_WAVES
-#define DERP_COST_MIN_WAVES 2
+#define DERP_COST_MIN_WAVES 3
+#endif
+#ifndef DERP_RANDOM_MIN_WAVES
+#define DERP_RANDOM_MIN_WAVES 2
 #endif
 #ifndef DERP_COST_BLOCK
 #define DERP_COST_BLOCK 64
 #endif
 #ifndef DERP_TILE_BLOCK
 #define DERP_TILE_BLOCK 4
+#endif
+// fp64 atan2 / division of the cost kernels' projection through the short routines of derp_camera.h (0 = the
+// device library's)
+#ifndef DERP_LEAN_PROJ
+#define DERP_LEAN_PROJ 1
 #endif
 static constexpr int kPadW = 1;   // ring of projWarp
 static constexpr int kPadC = 2;   // ring of projColor / projBias
@@ -176,40 +187,64 @@ struct LdsPairs {
   }
 };
 
-// computeSSD (DerpUtil.cpp:126-162) for one source whose projected tables are `col` / `bias`.
-__device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
-                                               const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc) {
+// The texels one computeSSD call reads, requested ahead of the arithmetic: the 4x4 block of projColor
+// around round(x, y) (rows yi-2..yi+1, cols xi-2..xi+1) and the 2x2 bias taps, as ten 16-byte loads. The
+// block lies inside the padded table for every x, y the tables can produce, and only the rare path at the
+// bottom of ssd_arith (taps not block shaped) ignores it.
+struct SsdTexels {
+  u4a8 raw[4][2];
+  u4a8 ba, bb;
+};
+__device__ __forceinline__ void ssd_issue(const LevelView& V, const ushort4* __restrict__ col,
+                                          const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc, SsdTexels& T) {
+  const int pitch = V.W + 2 * kPadC;
+  const int xi = (int)roundf(xDstSrc), yi = (int)roundf(yDstSrc);
+  // one table plane is far below 4 GB: 32-bit byte offsets from the (wave-uniform) plane base let the
+  // loads use the scalar-base + 32-bit-offset addressing form instead of 64-bit pointer arithmetic
+  const unsigned off = ((unsigned)(yi - 2 + kPadC) * (unsigned)pitch + (unsigned)(xi - 2 + kPadC)) * 8u;
+  const char* base = reinterpret_cast<const char*>(col);
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    T.raw[row][0] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u));
+    T.raw[row][1] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u + 16u));
+  }
+#ifdef DERP_ABLATE_NO_BIAS_LOAD  // developer ablation: same arithmetic, two loads fewer (results are wrong)
+  T.ba = T.raw[1][0];
+  T.bb = T.raw[2][0];
+  return;
+#endif
+  const unsigned boff = off + ((unsigned)pitch + 1u) * 8u;  // (yi - 1, xi - 1)
+  const char* bbase = reinterpret_cast<const char*>(bia);
+  T.ba = *reinterpret_cast<const u4a8*>(bbase + boff);
+  T.bb = *reinterpret_cast<const u4a8*>(bbase + (boff + (unsigned)pitch * 8u));
+}
+
+// computeSSD (DerpUtil.cpp:126-162) for one source whose projected tables are `col` / `bias`; `T` holds the
+// texels ssd_issue requested for (xDstSrc, yDstSrc).
+__device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
+                                             const SsdTexels& T, float xDstSrc, float yDstSrc) {
 #ifdef DERP_ABLATE_NO_SSD
   return {xDstSrc * 1e-3f, yDstSrc * 1e-3f};
 #endif
-  const int pitch = V.W + 2 * kPadC;
-  // The 4x4 texel block around round(x, y) (rows yi-2..yi+1, cols xi-2..xi+1) is requested here, together
-  // with the bias taps, so that one wait covers both; it lies inside the padded table for every x, y
-  // the tables can produce, and only the rare path at the bottom (taps not block shaped) ignores it.
-  u4a8 raw[4][2];
+#ifdef DERP_ABLATE_SSD_LOADS_ONLY  // developer ablation: the ten loads stay, the arithmetic is a few xors
   {
-    const int xi = (int)roundf(xDstSrc), yi = (int)roundf(yDstSrc);
-    // one table plane is far below 4 GB: 32-bit byte offsets from the (wave-uniform) plane base let the
-    // loads use the scalar-base + 32-bit-offset addressing form instead of 64-bit pointer arithmetic
-    const unsigned off = ((unsigned)(yi - 2 + kPadC) * (unsigned)pitch + (unsigned)(xi - 2 + kPadC)) * 8u;
-    const char* base = reinterpret_cast<const char*>(col);
-#pragma unroll
-    for (int row = 0; row < 4; ++row) {
-      raw[row][0] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u));
-      raw[row][1] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u + 16u));
+    unsigned a = T.ba.x ^ T.bb.y, b = T.ba.z ^ T.bb.w;
+    for (int r = 0; r < 4; ++r) {
+      a ^= T.raw[r][0].x ^ T.raw[r][0].z ^ T.raw[r][1].x ^ T.raw[r][1].z;
+      b ^= T.raw[r][0].y ^ T.raw[r][0].w ^ T.raw[r][1].y ^ T.raw[r][1].w;
     }
+    return {(float)(a & 0xffff) * 1e-3f + xDstSrc * 1e-3f, (float)(b & 0xffff) * 1e-3f + yDstSrc * 1e-3f};
   }
+#endif
+  const int pitch = V.W + 2 * kPadC;
+  const u4a8 (&raw)[4][2] = T.raw;
   // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
   float bias[3];
   {
     const float xf = roundf(xDstSrc), yf = roundf(yDstSrc);
-    const int xi = (int)xf, yi = (int)yf;
     const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
     const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
-    const unsigned off = ((unsigned)(yi - 1 + kPadC) * (unsigned)pitch + (unsigned)(xi - 1 + kPadC)) * 8u;
-    const char* base = reinterpret_cast<const char*>(bia);
-    const u4a8 a = *reinterpret_cast<const u4a8*>(base + off);
-    const u4a8 b = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)pitch * 8u));
+    const u4a8 a = T.ba, b = T.bb;
     // (B, G) as one packed pair, R alone — same per-lane operations as bilerp_u16
     const v2f sbBG = trunc2(splat2(w00) * bg_of(a.x) + splat2(w01) * bg_of(a.z) + splat2(w10) * bg_of(b.x) +
                             splat2(w11) * bg_of(b.z));
@@ -365,71 +400,112 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
   const float scale = 1.0f / (65535.0f * 65535.0f);
   return {first * scale, second * scale};
 }
+__device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
+                                               const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc) {
+  SsdTexels T;
+  ssd_issue(V, col, bia, xDstSrc, yDstSrc, T);
+  return ssd_arith(V, px, col, T, xDstSrc, yDstSrc);
+}
 
-// computeCost — Derp.cpp:104-226. `dl` = dst index inside the batch, `own` = dst2src.
-// Returns (cost, confidence); (FLT_MAX, 0) when fewer than kMinOverlappingCams-1 sources see it.
+// computeCost — Derp.cpp:104-226. `dl` = dst index inside the batch, `own` = dst2src. Returns (cost, confidence);
+// (FLT_MAX, 0) when fewer than kMinOverlappingCams-1 sources see the point. The reference's loop over the sources
+// (project, fetch the warp, computeSSD) runs as two phases — same arithmetic, same order of the SSD pairs:
+//  (i)  every source is projected (fp64 Camera::sees) and its projWarp taps are fetched; the taps of source
+//       s are consumed after the projection of source s + 1, so their latency hides behind that chain. What
+//       survives (visible, not NaN) leaves (xDstSrc, yDstSrc) in the lane's LDS slot of that source and a bit
+//       in `mask`; the wave keeps the union of the lanes' masks in a scalar.
+//  (ii) the wave walks the union; lanes holding the bit run computeSSD. The entry slots alias the pair array:
+//       the i-th pair of a lane is written after the entry of its i-th visible source (slot >= i) was read.
+// The fp64 projection state and the 4x4 texel block are never live together.
 __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int own, const PixCtx& px, float disparity,
                                                LdsPairs& pairs, unsigned& nPair) {
-  // dstToWorldPoint (DerpUtil.cpp:38-52): camDst.rig(p, 1.0f / disparity) — reciprocal in float
   const double depth = (double)(1.0f / disparity);
   const D3 pWorld = {px.rayO.x + px.rayD.x * depth, px.rayO.y + px.rayD.y * depth, px.rayO.z + px.rayD.z * depth};
   const size_t wPlane = warp_plane(V), cPlane = color_plane(V);
   const int wPitch = V.W + 2 * kPadW;
-  int ssdCount = 0;
-  for (int s = 0; s < V.S; ++s) {
-    if (s == own) {
-      continue;
-    }
-    const Cam& cs = V.camsSrc[s];
-    D2 pn;
-    // worldToSrcPoint (DerpUtil.cpp:56-73): Camera::sees on the normalised camera, then * (W, H)
+  unsigned mask = 0, waveMask = 0;
+  const ushort4* colBase = V.projColor + (size_t)dl * (V.S - 1) * cPlane;
+  const ushort4* biaBase = V.projBias + (size_t)dl * (V.S - 1) * cPlane;
+  {
+    bool pend = false;
+    int pendSlot = 0;
+    f4a8 pa = {0, 0, 0, 0}, pb = {0, 0, 0, 0};
+    float pxw = 0, pyw = 0;
+    auto consume = [&]() {
+      const float w00 = (1 - pxw) * (1 - pyw), w01 = pxw * (1 - pyw), w10 = (1 - pxw) * pyw, w11 = pxw * pyw;
+      const float wx = bilerp_f(pa.x, pa.z, pb.x, pb.z, w00, w01, w10, w11);
+      const float wy = bilerp_f(pa.y, pa.w, pb.y, pb.w, w00, w01, w10, w11);
+      // the reference adds a double literal: (float)((double)wx + 0.5). A sum of two floats rounded to
+      // double (53 >= 2 * 24 + 2 bits) and then to float equals the float sum, so one fp32 add does it
+      const float xDstSrc = wx + 0.5f, yDstSrc = wy + 0.5f;
+      const bool ok = pend && !(isnan(xDstSrc) || isnan(yDstSrc));
+      if (ok) {
+        pairs.set(pendSlot, SsdPair{xDstSrc, yDstSrc});
+        mask |= 1u << pendSlot;
+      }
+      if (__ballot(ok) != 0ull) {
+        waveMask |= 1u << pendSlot;
+      }
+    };
+    for (int s = 0; s < V.S; ++s) {
+      if (s == own) {
+        continue;
+      }
+      const Cam& cs = V.camsSrc[s];
+      D2 pn;
+      // worldToSrcPoint (DerpUtil.cpp:56-73): Camera::sees on the normalised camera, then * (W, H)
 #ifdef DERP_ABLATE_NO_PROJ
-    {
       const float fx = (float)pWorld.x * 0.07f + 0.013f * s, fy = (float)pWorld.y * 0.07f + 0.011f * s;
       pn.x = 0.5 + 0.45 * (double)(fx - floorf(fx) - 0.5f);
       pn.y = 0.5 + 0.45 * (double)(fy - floorf(fy) - 0.5f);
-      if ((s & 1) == 0) {
-        continue;
+      const bool vis = (s & 1) != 0;
+#else
+      const bool vis = sees<DERP_LEAN_PROJ != 0>(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1],
+                                                 1.0, 1.0, pn);
+#endif
+      if (__ballot(pend) != 0ull) {
+        consume();
+      }
+      pend = vis;
+      pendSlot = slot(s, own);
+      if (__ballot(vis) != 0ull) {
+        const float sx = (float)(pn.x * (double)V.W), sy = (float)(pn.y * (double)V.H);
+        // pDstSrc = getPixelBilinear(dstProjWarp, pSrc)
+        const float xf = roundf(sx), yf = roundf(sy);
+        const int xi = (int)xf, yi = (int)yf;
+        pxw = sx - xf + 0.5f;
+        pyw = sy - yf + 0.5f;
+        const size_t tab = (size_t)dl * (V.S - 1) + pendSlot;
+        // 32-bit byte offset from the wave-uniform plane base (scalar-base addressing form); lanes that do
+        // not see the source read the table's first taps
+        const char* wbase = reinterpret_cast<const char*>(V.projWarp + tab * wPlane);
+        const unsigned woff = vis ? ((unsigned)(yi - 1 + kPadW) * (unsigned)wPitch + (unsigned)(xi - 1 + kPadW)) * 8u : 0u;
+        pa = *reinterpret_cast<const f4a8*>(wbase + woff);
+        pb = *reinterpret_cast<const f4a8*>(wbase + (woff + (unsigned)wPitch * 8u));
       }
     }
-#else
-    if (!sees(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1], 1.0, 1.0, pn)) {
-      continue;
+    if (__ballot(pend) != 0ull) {
+      consume();
     }
-#endif
-    const float sx = (float)(pn.x * (double)V.W), sy = (float)(pn.y * (double)V.H);
-    const size_t tab = (size_t)dl * (V.S - 1) + slot(s, own);
-    // pDstSrc = getPixelBilinear(dstProjWarp, pSrc)
-    float xDstSrc, yDstSrc;
-    {
-      const float xf = roundf(sx), yf = roundf(sy);
-      const int xi = (int)xf, yi = (int)yf;
-      const float xw = sx - xf + 0.5f, yw = sy - yf + 0.5f;
-      const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
-      // 32-bit byte offset from the wave-uniform plane base (scalar-base addressing form)
-      const char* wbase = reinterpret_cast<const char*>(V.projWarp + tab * wPlane);
-      const unsigned woff = ((unsigned)(yi - 1 + kPadW) * (unsigned)wPitch + (unsigned)(xi - 1 + kPadW)) * 8u;
-      const f4a8 a = *reinterpret_cast<const f4a8*>(wbase + woff);
-      const f4a8 b = *reinterpret_cast<const f4a8*>(wbase + (woff + (unsigned)wPitch * 8u));
-      const float wx = bilerp_f(a.x, a.z, b.x, b.z, w00, w01, w10, w11);
-      const float wy = bilerp_f(a.y, a.w, b.y, b.w, w00, w01, w10, w11);
-      // the reference adds a double literal: (float)((double)wx + 0.5). A sum of two floats rounded to
-      // double (53 >= 2 * 24 + 2 bits) and then to float equals the float sum, so one fp32 add does it
-      xDstSrc = wx + 0.5f;
-      yDstSrc = wy + 0.5f;
-    }
-    if (isnan(xDstSrc) || isnan(yDstSrc)) {
-      continue;
-    }
-    ++nPair;
-    const SsdPair ssd =
-        compute_ssd(V, px, V.projColor + tab * cPlane, V.projBias + tab * cPlane, xDstSrc, yDstSrc);
-    pairs.set(ssdCount, ssd);
-    ++ssdCount;
   }
+  const int ssdCount = __popc(mask);
+  nPair += ssdCount;
   int keep = 1;  // kMinOverlappingCams - 1
   if (ssdCount < keep) {
     return make_float2(3.402823466e+38f, 0.0f);
+  }
+  {
+    int cnt = 0;
+    // waveMask is uniform by construction; readfirstlane keeps the walk (and the table bases) scalar
+    for (unsigned wm = __builtin_amdgcn_readfirstlane(waveMask); wm != 0; wm &= wm - 1) {
+      const int t = __builtin_ctz(wm);
+      if ((mask >> t) & 1) {
+        const SsdPair e = pairs.get(t);
+        const SsdPair ssd = compute_ssd(V, px, colBase + (size_t)t * cPlane, biaBase + (size_t)t * cPlane, e.first, e.second);
+        pairs.set(cnt, ssd);
+        ++cnt;
+      }
+    }
   }
   keep = max(keep, ssdCount - 2);
   GccSelect<LdsPairs> sel(pairs);
@@ -498,6 +574,17 @@ __global__ void k_bgr_to_bgrx(const uint16_t* __restrict__ in, ushort4* __restri
   for (; i < n; i += step) {
     out[i] = make_ushort4(in[3 * i], in[3 * i + 1], in[3 * i + 2], 0);
   }
+}
+
+__global__ void k_debug_atan2_ypos(const double* __restrict__ y, const double* __restrict__ x, double* __restrict__ out,
+                                   size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+#if defined(__HIP_DEVICE_COMPILE__)  // the routine exists in the device pass only
+  for (; i < n; i += step) {
+    out[i] = atan2_ypos(y[i], x[i]);
+  }
+#endif
 }
 
 // generateFovMasks — DerpUtil.cpp:239-276 (normalised camera: p = (x+.5, y+.5) / (W, H))
@@ -936,7 +1023,7 @@ __global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
     k_random_proposals(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
   const int dl = blockIdx.y;

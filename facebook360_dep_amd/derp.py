@@ -57,6 +57,7 @@ EXPORTS = [
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",
     "derp_stage_ping_pong", "derp_stage_mismatches", "derp_stage_bilateral_filter", "derp_stage_median_filter", "derp_stage_mask_fov",
     "derp_level_end", "derp_set_level_disparity", "derp_get_level_disparity", "derp_cost_map", "derp_debug_download",
+    "derp_debug_atan2_ypos",
     "derp_ssim", "derp_average_score", "derp_rephotograph", "derp_rephotograph_upload", "derp_rephotograph_render", "derp_canopy_cubemap",
     "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
@@ -335,6 +336,14 @@ class Derp:
         conf = np.zeros(self._shape(self._cur), dtype=np.float32)
         self._ck(lib().derp_cost_map(self.h, d, _p(disp), _p(cost), _p(conf)))
         return cost, conf
+
+    def debug_atan2_ypos(self, y, x):
+        """The cost kernels' own fp64 atan2(y >= 0, x) evaluated on the device."""
+        y = np.ascontiguousarray(y, np.float64)
+        x = np.ascontiguousarray(x, np.float64)
+        out = np.zeros_like(y)
+        self._ck(lib().derp_debug_atan2_ypos(self.h, _p(y), _p(x), _p(out), C.c_size_t(y.size)))
+        return out
 
     def debug(self, d, s, which):
         h, w = self._shape(self._cur)

@@ -26,6 +26,17 @@ BLOCK, CYCLIC = 0, 1
 KIND_COLOR, KIND_FG, KIND_DISPARITY = 0, 1, 2
 
 
+def disparity_crc(plane, crc=0):
+    """zlib CRC-32 of a float32 disparity plane (NaN payloads canonicalised), chained from `crc`."""
+    import zlib
+
+    import numpy as np
+
+    a = np.ascontiguousarray(plane, np.float32)
+    a = np.where(np.isnan(a), np.float32(np.nan), a).astype(np.float32)
+    return zlib.crc32(a.tobytes(), crc) & 0xFFFFFFFF
+
+
 # ---------------------------------------------------------------- host-only plan (no GPU needed)
 def temporal_window(t, first, last, radius):
     """populateMinMaxFrame (TemporalBilateralFilter.cpp:96-119): frames that exist in
@@ -179,6 +190,18 @@ class SequenceRunner:
     def download_disparity(self, frame, level, d):
         self.g.select_frame(self.slot(frame))
         return self.g.download_disparity(level, d)
+
+    def result_crc(self, level=0):
+        """{frame: CRC-32 of the frame's level-`level` disparity, destinations in rig order, float32 bytes with
+        every NaN written as 0x7fc00000} for every owned frame — what a multi-GPU run prints so that it can be
+        checked against the 1-GPU run."""
+        out = {}
+        for t in self.owned:
+            crc = 0
+            for d in range(self.g.D):
+                crc = disparity_crc(self.download_disparity(t, level, d), crc)
+            out[t] = crc
+        return out
 
     def buffer(self, frame, level, kind):
         p, n = C.c_void_p(), C.c_size_t()

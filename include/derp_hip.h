@@ -166,6 +166,9 @@ int derp_cost_map(derp_ctx* ctx, int dst, const float* disp, float* cost, float*
 /* tables of the current level: which = 0 projWarp (float2), 2 projColor (u16x3), 3 projColorBias
  * (u16x3), 4 variance of src (float), 5 fov mask of dst (u8; src ignored) */
 int derp_debug_download(derp_ctx* ctx, int dst, int src, int which, void* out);
+/* the cost kernels' own fp64 atan2 (FTHETA branch of Camera::cameraToSensor, Camera.h:306-309): out[i] =
+ * atan2(y[i], x[i]) for y >= 0, as the device routine computes it — so that a test can hold it against libm */
+int derp_debug_atan2_ypos(derp_ctx* ctx, const double* y, const double* x, double* out, size_t n);
 
 /* mismatch mask of the level processed last (dstMismatchedDisparityMask, PyramidLevel.h:332-338) */
 int derp_download_mismatch_mask(derp_ctx* ctx, int dst, uint8_t* out);

@@ -88,7 +88,7 @@ class OracleSequence:
     `sequence.SequenceRunner` over the HIP library)."""
 
     def __init__(self, rig, sizes, res, first, last, rank=0, world=1, radius=2, partition=0, threads=2,
-                 use_foreground_masks=False, frames=None, **opts):
+                 use_foreground_masks=False, frames=None, partial_coverage=True, **opts):
         import torch
 
         from facebook360_dep_amd import sequence, synth
@@ -96,6 +96,7 @@ class OracleSequence:
         self.rig, self.sizes, self.res = rig, sizes, res
         self.first, self.last, self.rank, self.world, self.radius = first, last, rank, world, radius
         self.threads, self.opts, self.use_fg, self.partition = threads, opts, use_foreground_masks, partition
+        self.partial_coverage = partial_coverage
         self.n = len(rig["cameras"])
         self.owned = sequence.owned_frames(first, last, world, rank, partition)
         self.halo = sequence.halo_frames(first, last, world, rank, radius, partition) if world > 1 else []
@@ -127,7 +128,8 @@ class OracleSequence:
             if level + 1 < len(self.sizes):
                 prev = [self.disp[t][level + 1][d].numpy() for d in range(self.n)]
             L = oracle_level(self.rig, self.sizes, self.frames[t], level, self.res, self.res, prev,
-                             partial_coverage=True, threads=self.threads, use_foreground_masks=self.use_fg,
+                             partial_coverage=self.partial_coverage, threads=self.threads,
+                             use_foreground_masks=self.use_fg,
                              **self.opts)
             L.process()
             for d in range(self.n):
@@ -135,6 +137,18 @@ class OracleSequence:
             self.raw[(t, level)] = self.disp[t][level].numpy().copy()
             if level not in self.fov:
                 self.fov[level] = np.stack([L.fov_mask(d) for d in range(self.n)])
+
+    def result_crc(self, level=0):
+        """Same definition as sequence.SequenceRunner.result_crc (bench.py's `result_crc`)."""
+        from facebook360_dep_amd import sequence
+
+        out = {}
+        for t in self.owned:
+            crc = 0
+            for d in range(self.n):
+                crc = sequence.disparity_crc(self.disp[t][level][d].numpy(), crc)
+            out[t] = crc
+        return out
 
     def tensor(self, frame, level, kind):
         src = {0: self.color, 1: self.fg, 2: self.disp}[kind][frame][level]

@@ -199,9 +199,80 @@ def test_sequence_sixteen_cameras_against_oracle(built):
         made.append((g, r))
     sequence.run_loopback([r for (_, r) in made], len(sizes) - 1)
     flips = _compare_with_oracle([r for (_, r) in made], ref, n, sizes)
-    print("16-camera sequence: %d float differences vs the oracle" % flips)
+    common.observed("sequence_sixteen_cameras_float_differences", flips)
     for (g, r) in made:
         g.close()
+
+
+def test_config3_full_size_two_ranks_equal_one(built):
+    """BASELINE config 3 at its own size — 16 cameras x 2048^2, 8 frames, full 10-level pyramid, temporal filter —
+    on one rank and on two ranks emulated on the GPU (loopback transport, own context / tables / frame slots
+    each): level-0 disparities bit-equal frame by frame, exchanged bytes = the plan's, NaN <=> outside the FOV
+    mask, median error against the analytic scene, and the CRCs bench.py prints for this workload."""
+    import json
+    import os
+
+    from facebook360_dep_amd import derp, sequence, synth
+
+    n, res, widths = synth.config("cfg2")
+    rig = synth.make_rig(n, res)
+    sizes = synth.level_sizes(res, res, widths)
+    first, last = 0, 7
+    w0, h0 = sizes[0]
+
+    truth = {}
+
+    def make(rank, world):
+        g = derp.Derp(rig["cameras"])
+        g.set_pyramid(sizes, res, res)
+        r = sequence.SequenceRunner(g, first, last, rank, world)
+        for t in r.owned:
+            frame = synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cuda")
+            r.upload_frame(t, frame)
+            for (tt, d) in ((0, 0), (5, 9)):
+                if tt == t:
+                    truth[(t, d)] = np.asarray(frame["truth"][d])
+        return g, r
+
+    g1, r1 = make(0, 1)
+    r1.run()
+    g1.synchronize()
+    crc1 = r1.result_crc()
+    # properties of the 1-rank result (the oracle cannot run this size): two frames, two destinations
+    for t, d in ((0, 0), (5, 9)):
+        got = r1.download_disparity(t, 0, d)
+        fov = g1.fov_mask(d, w0, h0).astype(bool)
+        assert np.array_equal(np.isnan(got), ~fov)
+        err = np.abs(got[fov] - truth[(t, d)][fov]) / truth[(t, d)][fov]
+        assert np.median(err) < 0.01, (t, d, float(np.median(err)))
+    keep = {(t, d): r1.download_disparity(t, 0, d) for t in (0, 3, 4, 7) for d in (0, 7, 15)}
+    g1.close()
+
+    made = [make(rank, 2) for rank in range(2)]
+    runners = [r for (_, r) in made]
+    assert [r.owned for r in runners] == [[0, 1, 2, 3], [4, 5, 6, 7]]
+    assert runners[0].halo == [4, 5] and runners[1].halo == [2, 3]
+    sequence.run_loopback(runners, len(sizes) - 1)
+    crc2 = {}
+    for r in runners:
+        crc2.update(r.result_crc())
+    assert crc2 == crc1
+    for (t, d), want in keep.items():
+        assert _bad(runners[t // 4].download_disparity(t, 0, d), want) == 0, (t, d)
+    plan = sequence.plan(first, last, 2, 2, 0)
+    px = sum(w * h for (w, h) in sizes)
+    assert len(plan) == 4
+    assert sum(r.stats()["bytes_received"] for r in runners) == len(plan) * px * n * (8 + 4)
+    for (g, r) in made:
+        g.close()
+    # the values bench.py's default workload prints at every --gpus N
+    got = {str(t): "%08x" % v for t, v in sorted(crc1.items())}
+    if os.environ.get("DERP_RECORD_BASELINE"):
+        with open(os.path.join(os.path.dirname(common._RECORD_PATH), "bench_result_crc_cfg2_8.json"), "w") as f:
+            json.dump(got, f, indent=1, sort_keys=True)
+    else:
+        with open(os.path.join(os.path.dirname(common._BASELINE_PATH), "bench_result_crc.json")) as f:
+            assert got == json.load(f)["cfg2_8"]
 
 
 def test_sequence_foreground_masks(built):
