@@ -94,6 +94,16 @@ __device__ __forceinline__ double div_plain(double n, double d) {
 // that it takes ONE division; <= 1 ulp from glibc's atan2 (test_lean_atan2_against_libm compares 4 x 10^6
 // arguments through derp_debug_atan2_ypos), like the device library's routine it replaces in the cost kernels,
 // at less than half its instruction count.
+// An fp64 literal for the hot chain, delivered in a scalar register pair at the point of use. gfx950 has no 64-bit
+// literal operands, and left alone the compiler parks every coefficient in a vector register pair hoisted out of
+// the candidate loop — two dozen registers that the allocator then spills to scratch INSIDE the dependent chain as
+// soon as anything else needs room (measured: +30 % on level-0 ping-pong). The opaque asm makes the value a
+// scalar one: if it is kept across the loop it costs scalar registers, whose spills are lane moves, not memory.
+// (Not volatile: a volatile asm is a scheduling barrier and serialises the two Horner chains, +25 %.)
+__device__ __forceinline__ double sk(double v) {
+  asm("" : "+s"(v));
+  return v;
+}
 __device__ __forceinline__ double atan2_ypos(double y, double x) {
   const double ax = fabs(x);
   const bool c0 = y < 0.4375 * ax, c1 = y < 0.6875 * ax, c2 = y < 1.1875 * ax, c3 = y < 2.4375 * ax;
@@ -101,26 +111,26 @@ __device__ __forceinline__ double atan2_ypos(double y, double x) {
   double num = __builtin_fma(-c, ax, y), den = __builtin_fma(c, y, ax);
   num = c0 ? y : c3 ? num : -ax;
   den = c0 ? ax : c3 ? den : y;
-  const double hi = c0 ? 0.0 : c1 ? 4.63647609000806093515e-01 : c2 ? 7.85398163397448278999e-01
-                     : c3 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00;
-  const double lo = c0 ? 0.0 : c1 ? 2.26987774529616870924e-17 : c2 ? 3.06161699786838301793e-17
-                     : c3 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17;
+  const double hi = c0 ? 0.0 : c1 ? sk(4.63647609000806093515e-01) : c2 ? sk(7.85398163397448278999e-01)
+                     : c3 ? sk(9.82793723247329054082e-01) : sk(1.57079632679489655800e+00);
+  const double lo = c0 ? 0.0 : c1 ? sk(2.26987774529616870924e-17) : c2 ? sk(3.06161699786838301793e-17)
+                     : c3 ? sk(1.39033110312309984516e-17) : sk(6.12323399573676603587e-17);
   const double t = div_plain(num, den);
   const double z = t * t, w = z * z;
-  double s1 = __builtin_fma(w, 1.62858201153657823623e-02, 4.97687799461593236017e-02);
-  s1 = __builtin_fma(w, s1, 6.66107313738753120669e-02);
-  s1 = __builtin_fma(w, s1, 9.09088713343650656196e-02);
-  s1 = __builtin_fma(w, s1, 1.42857142725034663711e-01);
-  s1 = __builtin_fma(w, s1, 3.33333333333329318027e-01);
+  double s1 = __builtin_fma(w, sk(1.62858201153657823623e-02), sk(4.97687799461593236017e-02));
+  s1 = __builtin_fma(w, s1, sk(6.66107313738753120669e-02));
+  s1 = __builtin_fma(w, s1, sk(9.09088713343650656196e-02));
+  s1 = __builtin_fma(w, s1, sk(1.42857142725034663711e-01));
+  s1 = __builtin_fma(w, s1, sk(3.33333333333329318027e-01));
   s1 = z * s1;
-  double s2 = __builtin_fma(w, -3.65315727442169155270e-02, -5.83357013379057348645e-02);
-  s2 = __builtin_fma(w, s2, -7.69187620504482999495e-02);
-  s2 = __builtin_fma(w, s2, -1.11111104054623557880e-01);
-  s2 = __builtin_fma(w, s2, -1.99999999998764832476e-01);
+  double s2 = __builtin_fma(w, sk(-3.65315727442169155270e-02), sk(-5.83357013379057348645e-02));
+  s2 = __builtin_fma(w, s2, sk(-7.69187620504482999495e-02));
+  s2 = __builtin_fma(w, s2, sk(-1.11111104054623557880e-01));
+  s2 = __builtin_fma(w, s2, sk(-1.99999999998764832476e-01));
   s2 = w * s2;
   double r = hi - ((t * (s1 + s2) - lo) - t);
   if (x < 0) {
-    r = 3.1415926535897931160E+00 - (r - 1.2246467991473531772E-16);
+    r = sk(3.1415926535897931160E+00) - (r - sk(1.2246467991473531772E-16));
   }
   return r;
 }

@@ -43,6 +43,10 @@ namespace derp {
 #endif
 // fp64 atan2 / division of the cost kernels' projection through the short routines of derp_camera.h (0 = the
 // device library's)
+// skip, per wave, the sources that face away from the wave's pixels for every candidate depth (behind_sources)
+#ifndef DERP_SOURCE_CULL
+#define DERP_SOURCE_CULL 1
+#endif
 #ifndef DERP_LEAN_PROJ
 #define DERP_LEAN_PROJ 1
 #endif
@@ -407,6 +411,33 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
   return ssd_arith(V, px, col, T, xDstSrc, yDstSrc);
 }
 
+// Sources that cannot see this wave's pixels at ANY candidate depth: the pixel's ray O + t D, pushed through a
+// source's backward axis b (third row of its rotation), is linear in t — backward(t) = b.(O - pos) + t b.D. If that is
+// positive with a margin at t = kCullMinDepth and grows with t (b.D > margin), the point is behind the source's
+// image plane for every t >= kCullMinDepth, where Camera::sees (Camera.h:184-190, the isBehind / FOV-cone test)
+// returns false for every camera whose FOV half-angle is <= 90 degrees (cos_fov >= 0). The margins (1e-6) are ten
+// orders of magnitude above the rounding error of the fp64 evaluation in `sees`, so skipping these sources cannot
+// change a result; a source is skipped only when EVERY active lane of the wave agrees (the mask is wave-uniform).
+// On the 16-camera rig 8-9 of the 15 sources face away from any given tile: their per-candidate cone tests (and
+// the scalar-cache round trip for their constants) were ~5 % of the ping-pong kernel.
+static constexpr double kCullMinDepth = 0.05;  // m; candidates nearer than this (disparity > 20) take the full loop
+__device__ __forceinline__ unsigned behind_sources(const LevelView& V, int own, const PixCtx& px) {
+  unsigned cull = 0;
+  for (int s = 0; s < V.S; ++s) {
+    if (s == own) {
+      continue;
+    }
+    const Cam& cs = V.camsSrc[s];
+    const double a = sum3(cs.R[6] * (px.rayO.x - cs.pos[0]), cs.R[7] * (px.rayO.y - cs.pos[1]), cs.R[8] * (px.rayO.z - cs.pos[2]));
+    const double b = sum3(cs.R[6] * px.rayD.x, cs.R[7] * px.rayD.y, cs.R[8] * px.rayD.z);
+    const bool behind = cs.cos_fov >= 0 && b > 1e-6 && a + kCullMinDepth * b > 1e-6;
+    if (__ballot(!behind) == 0ull) {
+      cull |= 1u << slot(s, own);
+    }
+  }
+  return __builtin_amdgcn_readfirstlane(cull);
+}
+
 // computeCost — Derp.cpp:104-226. `dl` = dst index inside the batch, `own` = dst2src. Returns (cost, confidence);
 // (FLT_MAX, 0) when fewer than kMinOverlappingCams-1 sources see the point. The reference's loop over the sources
 // (project, fetch the warp, computeSSD) runs as two phases — same arithmetic, same order of the SSD pairs:
@@ -417,13 +448,17 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
 //  (ii) the wave walks the union; lanes holding the bit run computeSSD. The entry slots alias the pair array:
 //       the i-th pair of a lane is written after the entry of its i-th visible source (slot >= i) was read.
 // The fp64 projection state and the 4x4 texel block are never live together.
+// `cull` (wave-uniform, from behind_sources): slots of sources that no lane of the wave can see at any depth >=
+// kCullMinDepth; they are skipped without their cone test. 0 = test every source.
 __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int own, const PixCtx& px, float disparity,
-                                               LdsPairs& pairs, unsigned& nPair) {
+                                               LdsPairs& pairs, unsigned& nPair, unsigned cull = 0) {
   const double depth = (double)(1.0f / disparity);
   const D3 pWorld = {px.rayO.x + px.rayD.x * depth, px.rayO.y + px.rayD.y * depth, px.rayO.z + px.rayD.z * depth};
   const size_t wPlane = warp_plane(V), cPlane = color_plane(V);
   const int wPitch = V.W + 2 * kPadW;
   unsigned mask = 0, waveMask = 0;
+  // the cull mask holds for depths >= kCullMinDepth only (NaN and negative depths fail the comparison too)
+  cull = __builtin_amdgcn_readfirstlane(__ballot(!(depth >= kCullMinDepth)) != 0ull ? 0u : cull);
   const ushort4* colBase = V.projColor + (size_t)dl * (V.S - 1) * cPlane;
   const ushort4* biaBase = V.projBias + (size_t)dl * (V.S - 1) * cPlane;
   {
@@ -448,7 +483,7 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       }
     };
     for (int s = 0; s < V.S; ++s) {
-      if (s == own) {
+      if (s == own || ((cull >> slot(s, own)) & 1u)) {
         continue;
       }
       const Cam& cs = V.camsSrc[s];
@@ -1042,9 +1077,10 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
       } else if (random_gate(V, d, own, idx)) {
         PixCtx px;
         load_pixctx(V, d, own, x, y, px);
+        const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, own, px) : 0u;
         float currDisp = disp[idx];
         unsigned before = nPair;
-        float2 cur = compute_cost(V, dl, own, px, currDisp, pairs, nPair);
+        float2 cur = compute_cost(V, dl, own, px, currDisp, pairs, nPair, cull);
         ++nCost;
         unsigned currPairs = nPair - before;
         float currCost = cur.x, currConf = cur.y;
@@ -1058,7 +1094,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
           const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
           const float propDisp = minstd_uniform(state, lo, hi);
           before = nPair;
-          const float2 pr = compute_cost(V, dl, own, px, propDisp, pairs, nPair);
+          const float2 pr = compute_cost(V, dl, own, px, propDisp, pairs, nPair, cull);
           ++nCost;
           if (pr.x < currCost && pr.x < costThresh) {
             currCost = pr.x;
@@ -1107,6 +1143,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
       } else if (!(V.srcVar[(size_t)own * n + idx] < V.varNoiseFloor)) {
         PixCtx px;
         load_pixctx(V, d, own, x, y, px);
+        const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, own, px) : 0u;
         float bestCost = __builtin_inff();
         float bestDisp = outDisp;
         const float bg = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : 0.f;
@@ -1126,7 +1163,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
                 nPair += V.pairCount[(size_t)d * n + idx];
                 ++nMemo;
               } else {
-                r = compute_cost(V, dl, own, px, cand, pairs, nPair);
+                r = compute_cost(V, dl, own, px, cand, pairs, nPair, cull);
               }
               ++nCost;
               if (r.x < bestCost) {
