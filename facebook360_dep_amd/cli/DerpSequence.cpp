@@ -3,9 +3,15 @@
 // DerpCLI(level) on every frame -> TemporalBilateralFilter(level) over [t - R, t + R] -> "Transfer" (the
 // filtered level overwrites disparity_levels/level_L) -> next level. The reference runs those three steps as
 // separate worker jobs that hand frames over through the file system; here the frames of a chunk stay
-// resident in HBM (frame slots), and with several GPUs each process owns a contiguous chunk of the frames
-// (render.py:169-175) and exchanges only the halo frames' raw level disparity over RCCL (derp_seq_*,
-// include/derp_hip.h) — C++ host + HIP + RCCL, no Python in the loop.
+// resident in HBM (frame slots) — or, with --resident_frames N, stream level by level through N slots from host
+// memory, so that the sequence length is bounded by host RAM, not by HBM — and with several GPUs each process
+// owns a contiguous chunk of the frames (render.py:169-175) and exchanges only the halo frames' raw level
+// disparity over RCCL (derp_seq_*, include/derp_hip.h) — C++ host + HIP + RCCL, no Python in the loop.
+//
+// I/O schedule: decoding starts before the HIP runtime does. The worker pool inflates every frame's coarse
+// levels first (a quarter of the bytes), then the finest level frame by frame; the level loop consumes a
+// (frame, level) as soon as it is decoded, so the finest level's PNGs inflate behind the coarse levels' compute
+// and frame k + 1's behind frame k's. Results are written by the pool behind the next level.
 //
 // Flags: DerpCLI's (DerpCLI.cpp:40-67) + TemporalBilateralFilter's filter flags (:51-59) + the pipeline's
 // do_temporal_filter / do_temporal_masking (pipeline.py:378,386). Inputs and outputs are the files the three
@@ -50,13 +56,16 @@ int main(int argc, char** argv) {
   F.boolean("do_temporal_masking", false, "use foreground masks in the temporal filter [extension: pipeline.py do_temporal_masking]");
   F.dbl("sigma", 0.01, "spatio-temporal smoothing [extension: TemporalBilateralFilter --sigma]");
   F.i32("space_radius", -1, "space filtering radius [extension: TemporalBilateralFilter --space_radius]");
-  F.i32("time_radius", 2, "temporal filtering radius [extension: TemporalBilateralFilter --time_radius]");
+  F.i32("time_radius", 2, "temporal filtering radius, at most 15 [extension: TemporalBilateralFilter --time_radius]");
   F.dbl("weight_b", 0.5, "Blue channel weight [extension: TemporalBilateralFilter --weight_b]");
   F.dbl("weight_g", 1.0, "Green channel weight [extension: TemporalBilateralFilter --weight_g]");
   F.dbl("weight_r", 1.0, "Red channel weight [extension: TemporalBilateralFilter --weight_r]");
   F.i32("gpus", 1, "fork one process per GPU of this node (1 = this process only) [extension]");
   F.str("partition", "block", "frames per rank: block (contiguous chunks) | cyclic [extension]");
   F.str("rccl_id_file", "", "file through which rank 0 hands the RCCL unique id to the other ranks [extension]");
+  F.i32("resident_frames", 0,
+        "frames kept in HBM per GPU: 0 = all of them; N >= 2 * time_radius + 1 = out of core, the other frames stream "
+        "level by level from host memory [extension]");
   F.parse(argc, argv);
   Timer total;
   // RCCL's peer-memory handles need the dmabuf IPC mode on this driver stack; keep the caller's choice if any
@@ -65,6 +74,9 @@ int main(int argc, char** argv) {
   // ---- ranks: --gpus forks them; otherwise RANK / WORLD_SIZE / LOCAL_RANK from the environment
   int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), localRank = env_int("LOCAL_RANK", -1);
   std::string idFile = F.s("rccl_id_file");
+  // a nonce every rank of ONE job agrees on: a stale id file of an earlier job is told apart by it
+  std::string nonce = std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "") + ":" +
+                      (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "");
   if (F.i("gpus") > 1 && world == 1) {
     world = F.i("gpus");
     CHECK_MSG(F.s("output_root") != "", "output_root");
@@ -72,6 +84,7 @@ int main(int argc, char** argv) {
     if (idFile.empty()) {
       idFile = (fs::path(F.s("output_root")) / fmt(".derp_rccl_id.%d", (int)getpid())).string();
     }
+    nonce = fmt("pid%d:%ld", (int)getpid(), (long)time(nullptr));
     fs::remove(idFile);
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {  // fork before any HIP call
@@ -87,20 +100,17 @@ int main(int argc, char** argv) {
     }
     if (!kids.empty()) {  // the parent only waits: a failing rank fails the job and takes the others down with it
       int failed = 0;        // (a rank that died would leave its peers blocked in the RCCL rendezvous / exchange)
-      size_t alive = kids.size();
-      while (alive > 0) {
+      while (!kids.empty()) {
         int st = 0;
         const pid_t done = waitpid(-1, &st, 0);
         if (done < 0) {
           break;
         }
-        --alive;
+        kids.erase(std::remove(kids.begin(), kids.end(), done), kids.end());  // reaped: its pid may be reused
         if (!(WIFEXITED(st) && WEXITSTATUS(st) == 0)) {
           ++failed;
-          for (pid_t k : kids) {
-            if (k != done) {
-              kill(k, SIGTERM);  // harmless for ranks that already exited
-            }
+          for (pid_t k : kids) {  // only ranks that are still our un-reaped children
+            kill(k, SIGTERM);
           }
         }
       }
@@ -113,9 +123,41 @@ int main(int argc, char** argv) {
     }
   }
   CHECK_MSG(rank >= 0 && rank < world, "RANK < WORLD_SIZE");
+  if (world > 1 && !F.s("log_dir").empty() && log_file()) {  // one log file per rank
+    fclose(log_file());
+    log_file() = fopen((fs::path(F.s("log_dir")) / fmt("%s.rank%d.INFO", F.program.c_str(), rank)).c_str(), "w");
+  }
 
   DerpJob J(F);
-  J.setup(world > 1 ? (localRank >= 0 ? localRank : rank) : -1);
+  J.setup_host();
+  CHECK_MSG(F.s("partition") == "block" || F.s("partition") == "cyclic", "partition is block or cyclic");
+  CHECK_MSG(F.i("time_radius") >= 0 && F.i("time_radius") <= 15, "time_radius in 0..15 (the filter kernel's window holds 31 frames)");
+  const int partition = F.s("partition") == "block" ? DERP_SEQ_BLOCK : DERP_SEQ_CYCLIC;
+  const int first = J.firstFrame, last = J.firstFrame + J.numFrames - 1;
+  std::vector<int> owned;
+  for (int t = first; t <= last; ++t) {
+    if (derp_seq_owner(first, last, world, partition, t) == rank) {
+      owned.push_back(t);
+    }
+  }
+  const int nOwned = (int)owned.size();
+
+  // ---- decoding starts now, before the HIP runtime: coarse levels of every frame first, then the finest level
+  // frame by frame (the order the level loop consumes them in)
+  IoPool pool(F.i("threads"));
+  FrameStore store(J, pool, owned);
+  for (int level = store.inTop; level > J.levelEnd; --level) {
+    for (int k = 0; k < nOwned; ++k) {
+      store.start_decode(k, level);
+    }
+  }
+  for (int k = 0; k < nOwned; ++k) {
+    store.start_decode(k, J.levelEnd);
+  }
+
+  const double tHost = total.s();
+  J.setup_device(world > 1 ? (localRank >= 0 ? localRank : rank) : -1);
+  const double tDevice = total.s();
   J.create_output_dirs({"disparity_time_filtered_levels"});
   derp_ctx* ctx = J.ctx;
 
@@ -129,74 +171,87 @@ int main(int argc, char** argv) {
   so.space_radius = F.i("space_radius");
   so.use_foreground_masks = F.b("do_temporal_masking");
   so.do_temporal_filter = F.b("do_temporal_filter");
-  CHECK_MSG(F.s("partition") == "block" || F.s("partition") == "cyclic", "partition is block or cyclic");
-  so.partition = F.s("partition") == "block" ? DERP_SEQ_BLOCK : DERP_SEQ_CYCLIC;
+  so.partition = partition;
+  so.resident_frames = F.i("resident_frames");
   CHECK_MSG(!so.use_foreground_masks || J.useFg, "do_temporal_masking needs --use_foreground_masks (the masks must be loaded)");
-  const int first = J.firstFrame, last = J.firstFrame + J.numFrames - 1;
   derp_seq* seq = nullptr;
   DERP_OK(ctx, derp_seq_create(&seq, ctx, first, last, rank, world, &so));
-  int nOwned = 0, nHalo = 0;
-  derp_seq_counts(seq, &nOwned, &nHalo);
-  std::vector<int> owned(std::max(nOwned, 1));
-  derp_seq_frames(seq, 0, owned.data(), nOwned);
-  owned.resize(nOwned);
-  LOG_INFO(fmt("rank %d of %d: %d frame(s) owned, %d halo frame(s)", rank, world, nOwned, nHalo));
+  int nHalo = 0, nSlots = 0;
+  derp_seq_counts(seq, nullptr, &nHalo);
+  derp_frame_slots(ctx, &nSlots, nullptr);
+  LOG_INFO(fmt("rank %d of %d: %d frame(s) owned, %d halo frame(s), %d frame slot(s) in HBM%s", rank, world, nOwned, nHalo,
+               nSlots, nSlots < nOwned ? " (out of core)" : ""));
 
   if (world > 1) {  // RCCL communicator: rank 0 publishes the unique id through a file
     CHECK_MSG(!idFile.empty(), "--rccl_id_file (a path every rank can read) is needed when WORLD_SIZE > 1");
+    // file = [128-byte id][nonce]: ranks started by hand (RANK / WORLD_SIZE) may find the file of an earlier job
+    // under the same name; they wait until the nonce is this job's
     unsigned char id[128];
     if (rank == 0) {
+      fs::remove(idFile);
       CHECK_MSG(derp_rccl_unique_id(id, sizeof id) == 0, "ncclGetUniqueId failed (librccl not loadable?)");
       const std::string tmp = idFile + ".tmp";
       {
         std::ofstream f(tmp, std::ios::binary);
         f.write(reinterpret_cast<const char*>(id), sizeof id);
+        f.write(nonce.data(), (std::streamsize)nonce.size());
       }
       fs::rename(tmp, idFile);
     } else {
       Timer t;
-      while (!fs::exists(idFile) || fs::file_size(idFile) < sizeof id) {
+      for (;;) {
+        std::error_code ec;
+        if (fs::exists(idFile, ec) && fs::file_size(idFile, ec) == sizeof id + nonce.size()) {
+          std::ifstream f(idFile, std::ios::binary);
+          std::string got(nonce.size(), '\0');
+          f.read(reinterpret_cast<char*>(id), sizeof id);
+          f.read(&got[0], (std::streamsize)got.size());
+          if (f && got == nonce) {
+            break;
+          }
+        }
         CHECK_MSG(t.s() < 300, "timed out waiting for " + idFile);
         usleep(20000);
       }
-      std::ifstream f(idFile, std::ios::binary);
-      f.read(reinterpret_cast<char*>(id), sizeof id);
     }
     DERP_OK(ctx, derp_seq_attach_rccl(seq, id, sizeof id));
     DERP_OK(ctx, derp_seq_selftest(seq, 4096));
+    if (rank == 0 && F.i("gpus") <= 1) {
+      fs::remove(idFile);  // every rank has joined the communicator: the next job must not find this id
+    }
   }
 
-  // ---- inputs: every owned frame into its slot (decode of frame k + 1 overlaps the upload of frame k)
-  IoPool pool(F.i("threads"));
-  {
-    FrameStager stager(J, pool);
-    if (nOwned) {
-      stager.start_decode(owned[0], 0);
-    }
-    for (int k = 0; k < nOwned; ++k) {
-      stager.wait(k & 1);
-      if (k + 1 < nOwned) {
-        stager.start_decode(owned[k + 1], (k & 1) ^ 1);
-      }
-      DERP_OK(ctx, derp_select_frame(ctx, derp_seq_frame_slot(seq, owned[k])));
-      stager.upload(k & 1);
-    }
-    LOG_INFO(fmt("-- inputs of %d frame(s) resident in HBM after %.3fs (decode wait %.3fs, upload %.3fs)", nOwned,
-                 total.s(), stager.waited, stager.uploading));
-  }
-  DERP_OK(ctx, derp_seq_exchange_inputs(seq));  // colour guides (+ masks) of the halo frames, once
-
+  LOG_INFO(fmt("-- start-up: flags + rig + input check %.3fs, HIP runtime + context %.3fs, output dirs + frame slots + "
+               "communicator %.3fs (images decoding since %.3fs)", tHost, tDevice - tHost, total.s() - tDevice, tHost));
   // ---- the level loop (pipeline.py:364-408)
   LevelWriter writer(J, pool);
-  double tCompute = 0;
+  double tCompute = 0, tUpload = 0;
   const std::vector<fs::path> dirs = so.do_temporal_filter
       ? std::vector<fs::path>{J.dispLevels, fs::path(J.outputRoot) / "disparity_time_filtered_levels"}
       : std::vector<fs::path>{J.dispLevels};
+  if (store.inTop > J.levelStart) {  // coarse masks / the previous level of a resumed run (DerpCLI.cpp:280-288)
+    for (int k = 0; k < nOwned; ++k) {
+      store.wait(k, store.inTop);
+      store.hand_over(seq, k, store.inTop, nSlots >= nOwned);
+    }
+  }
   for (int level = J.levelStart; level >= J.levelEnd; --level) {
     LOG_INFO(fmt("Processing level %d of %d frame(s)", level, nOwned));
+    for (int k = 0; k < nOwned; ++k) {
+      store.wait(k, level);  // this frame's level is decoded (the pool is busy with later frames / finer levels)
+      Timer t;
+      store.hand_over(seq, k, level, nSlots >= nOwned);
+      tUpload += t.s();
+      DERP_OK(ctx, derp_seq_level_compute_frame(seq, level, owned[k]));
+    }
     {
       Timer t;
-      DERP_OK(ctx, derp_seq_level_compute(seq, level));
+      if (nOwned == 0) {
+        DERP_OK(ctx, derp_seq_level_compute(seq, level));
+      }
+      if (world > 1) {
+        DERP_OK(ctx, derp_seq_exchange_inputs_level(seq, level));  // colour guides (+ masks) of the halo frames
+      }
       DERP_OK(ctx, derp_seq_level_exchange(seq, level));
       DERP_OK(ctx, derp_seq_level_filter(seq, level));
       DERP_OK(ctx, derp_synchronize(ctx));
@@ -205,8 +260,8 @@ int main(int argc, char** argv) {
     const int parity = level & 1;
     writer.begin(parity, J.npx(level) * 4 * J.D * std::max(nOwned, 1));
     for (int k = 0; k < nOwned; ++k) {
-      DERP_OK(ctx, derp_select_frame(ctx, derp_seq_frame_slot(seq, owned[k])));
-      writer.save(parity, J.npx(level) * 4 * J.D * k, level, zero_pad(owned[k]), dirs);
+      // PNG only at the finest level: the pipeline forces PFM above it (pipeline.py:366-369)
+      writer.save_seq(seq, owned[k], parity, J.npx(level) * 4 * J.D * k, level, zero_pad(owned[k]), dirs, level == J.levelEnd);
     }
     LOG_INFO(fmt("-- Elapsed time: %.3fs wall (level %d)", total.s(), level));
   }
@@ -214,9 +269,10 @@ int main(int argc, char** argv) {
   uint64_t sent = 0, received = 0;
   double exchangeMs = 0;
   derp_seq_stats(seq, &sent, &received, &exchangeMs);
-  LOG_INFO(fmt("-- rank %d: compute + exchange + filter %.3fs, halo exchange %.1f MB received / %.1f MB sent in %.1f ms on "
-               "the stream, download %.3fs, waited for writes %.3fs",
-               rank, tCompute, received / 1e6, sent / 1e6, exchangeMs, writer.downloading, writer.waited));
+  LOG_INFO(fmt("-- rank %d: waited for decode %.3fs, input hand-over %.3fs, exchange + filter %.3fs, halo exchange %.1f MB "
+               "received / %.1f MB sent in %.1f ms on the stream, download %.3fs, waited for writes %.3fs",
+               rank, store.waited, tUpload, tCompute, received / 1e6, sent / 1e6, exchangeMs, writer.downloading,
+               writer.waited));
   char name[256];
   derp_device_name(ctx, name, sizeof name);
   LOG_INFO(fmt("-- TOTAL: %.3fs wall on %s (rank %d of %d)", total.s(), name, rank, world));

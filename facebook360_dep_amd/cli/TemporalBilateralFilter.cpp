@@ -81,7 +81,8 @@ int main(int argc, char** argv) {
   const int level = F.i("level");
   const bool useFg = F.b("use_foreground_masks");
   auto levelDir = [&](const std::string& base) { return fs::path(base) / ("level_" + std::to_string(level)); };
-  bool savePng = F.s("output_formats").find("png") != std::string::npos;
+  const bool savePng = F.s("output_formats").find("png") != std::string::npos;
+  const bool saveExr = F.s("output_formats").find("exr") != std::string::npos;
 
   for (int cur = std::stoi(F.s("first")); cur <= std::stoi(F.s("last")); ++cur) {  // filterFrame, :121-184
     int first = 0, last = INT32_MAX;
@@ -135,6 +136,9 @@ int main(int argc, char** argv) {
       write_pfm(dir / (zero_pad(cur) + ".pfm"), out.data(), w, h);
       if (savePng) {
         write_disparity_png(dir / (zero_pad(cur) + ".png"), out.data(), w, h);
+      }
+      if (saveExr) {
+        write_exr_f32(dir / (zero_pad(cur) + ".exr"), out.data(), w, h);
       }
     }
   }

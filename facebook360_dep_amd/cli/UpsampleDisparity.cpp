@@ -132,6 +132,8 @@ int main(int argc, char** argv) {
           write_pfm(dir / (frame + ".pfm"), up.data(), wUp, hUp);
         } else if (ext == "png" || ext == ".png") {
           write_disparity_png(dir / (frame + ".png"), up.data(), wUp, hUp);
+        } else if (ext == "exr" || ext == ".exr") {
+          write_exr_f32(dir / (frame + ".exr"), up.data(), wUp, hUp);
         } else if (!ext.empty()) {
           LOG_WARNING("output format not supported by this build: " + ext);
         }

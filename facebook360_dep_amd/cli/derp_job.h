@@ -47,7 +47,7 @@ struct DerpJob {
   int S = 0, D = 0;
   std::map<int, std::pair<int, int>> sizes;
   int numLevels = 0, levelStart = 0, levelEnd = 0, firstFrame = 0, numFrames = 0;
-  bool useFg = false, savePng = false;
+  bool useFg = false, savePng = false, saveExr = false;
   std::string inputRoot, outputRoot;
   fs::path dispLevels;
   std::vector<int> W, H;
@@ -60,6 +60,12 @@ struct DerpJob {
 
   // verifyInputs + rig + pyramid geometry (DerpCLI.cpp:69-218); `device` overrides --device when >= 0
   void setup(int device = -1) {
+    setup_host();
+    setup_device(device);
+  }
+  // everything that needs no GPU: flags, rig, level sizes, input verification — image decoding can start right
+  // after it, while setup_device pays for the HIP start-up and the table allocations
+  void setup_host() {
     CHECK_MSG(F.s("input_root") != "", "input_root");
     CHECK_MSG(F.s("output_root") != "", "output_root");
     if (F.i("level_start") >= 0 && F.i("level_end") >= 0) {
@@ -92,18 +98,10 @@ struct DerpJob {
     {
       std::stringstream ss(F.s("output_formats"));
       std::string f;
-      bool anyOther = false, exr = false;
       while (std::getline(ss, f, ',')) {
         CHECK_MSG(f.empty() || f == "exr" || f == "png" || f == "pfm", "Invalid output format specified: " + f);
         savePng |= f == "png";
-        exr |= f == "exr";
-        anyOther |= f == "png" || f == "pfm";
-      }
-      // PyramidLevel.h:515-516 writes .exr through OpenCV; this build has no EXR encoder. Asking for exr ALONE
-      // fails loudly; next to png / pfm it is skipped with a warning (pfm is always written, like the reference)
-      CHECK_MSG(!exr || anyOther, "output format exr is not supported by this build (pfm and png are)");
-      if (exr) {
-        LOG_WARNING("exr output is not supported by this build; pfm is always written");
+        saveExr |= f == "exr";  // PyramidLevel.h:515-516; pfm is always written, like the reference (:494)
       }
       if (F.s("output_formats").empty()) {
         LOG_WARNING("No explicit output formats specified. Forcing PFM...");
@@ -152,6 +150,17 @@ struct DerpJob {
     fs::create_directories(outputRoot);
     widthFull = (int)rigDst[0].resolution[0];
     heightFull = (int)rigDst[0].resolution[1];
+    // levels outside [levelEnd, min(levelStart + 1, numLevels - 1)] are declared absent (no HBM spent on them)
+    W.assign(numLevels, 0);
+    H.assign(numLevels, 0);
+    const int topLevel = std::min(levelStart + 1, numLevels - 1);
+    for (int l = levelEnd; l <= topLevel; ++l) {
+      CHECK_MSG(sizes.count(l), fmt("no images found for level %d", l));
+      W[l] = sizes[l].first;
+      H[l] = sizes[l].second;
+    }
+  }
+  void setup_device(int device = -1) {
     // ---- context
     if (derp_create(&ctx, device >= 0 ? device : F.i("device"), rigSrc.data(), S, rigDst.data(), D) != 0) {
       LOG_FATAL(std::string("derp_create failed: ") + derp_last_error(nullptr));
@@ -171,15 +180,6 @@ struct DerpJob {
     opt.partial_coverage = F.b("partial_coverage");
     opt.rebuild_warp_tables = 0;  // warps depend on rig + level size only: build once, reuse across frames
     DERP_OK(ctx, derp_set_options(ctx, &opt));
-    // levels outside [levelEnd, min(levelStart + 1, numLevels - 1)] are declared absent (no HBM spent on them)
-    W.assign(numLevels, 0);
-    H.assign(numLevels, 0);
-    const int topLevel = std::min(levelStart + 1, numLevels - 1);
-    for (int l = levelEnd; l <= topLevel; ++l) {
-      CHECK_MSG(sizes.count(l), fmt("no images found for level %d", l));
-      W[l] = sizes[l].first;
-      H[l] = sizes[l].second;
-    }
     DERP_OK(ctx, derp_set_pyramid(ctx, numLevels, W.data(), H.data(), widthFull, heightFull));
   }
 
@@ -369,6 +369,179 @@ struct FrameStager {
   }
 };
 
+// The inputs of a rank's frames in host memory, decoded level by level (DerpSequence): one buffer per (frame,
+// level), one batch of pool jobs per (frame, level) that the level loop waits for individually, handed to the
+// sequence driver with derp_seq_host_inputs (resident mode: uploaded then; out of core: streamed by the library
+// whenever the frame's level is needed — the buffers stay alive until the store is destroyed).
+struct FrameStore {
+  const DerpJob& J;
+  IoPool& pool;
+  std::vector<int> frames;
+  int inTop;
+  // uninitialised host memory (a value-initialising container would write 4 GB of zeros before the first decode)
+  template <typename T>
+  struct Raw {
+    T* p = nullptr;
+    size_t n = 0;
+    Raw() = default;
+    Raw(const Raw&) = delete;
+    Raw& operator=(const Raw&) = delete;
+    Raw(Raw&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+    ~Raw() { free(p); }
+    void resize(size_t count) {
+      free(p);
+      p = static_cast<T*>(malloc(count * sizeof(T)));
+      CHECK_MSG(p != nullptr || count == 0, "out of host memory");
+      n = count;
+    }
+    T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+  };
+  struct Level {
+    Raw<uint16_t> color;  // [S][n][3]
+    Raw<uint8_t> mask;    // [S][n]
+    Raw<float> bg, prev;  // [D][n]
+    std::unique_ptr<IoBatch> batch;
+  };
+  std::vector<std::vector<Level>> data;  // [frame index][level]
+  double waited = 0;
+
+  FrameStore(const DerpJob& job, IoPool& p, const std::vector<int>& owned) : J(job), pool(p), frames(owned) {
+    inTop = J.levelStart < J.numLevels - 1 ? J.levelStart + 1 : J.levelStart;
+    data.resize(frames.size());
+    for (auto& f : data) {
+      f.resize(J.numLevels);
+      for (auto& l : f) {
+        l.batch.reset(new IoBatch);
+      }
+    }
+  }
+  ~FrameStore() {
+    for (auto& f : data) {
+      for (auto& l : f) {
+        std::unique_lock<std::mutex> lk(l.batch->mu);
+        l.batch->cv.wait(lk, [&] { return l.batch->pending == 0; });
+      }
+    }
+    for (auto& b : bounce) {
+      b.release();
+    }
+  }
+
+  void start_decode(int k, int level) {
+    const std::string frameName = zero_pad(frames[k]);
+    Level& L = data[k][level];
+    IoBatch& B = *L.batch;
+    const Flags& F = J.F;
+    const int w = J.W[level], h = J.H[level];
+    const size_t n = J.npx(level);
+    const bool compute = level <= J.levelStart;  // level inTop > levelStart only feeds the upsample
+    if (compute) {
+      L.color.resize(n * 3 * J.S);
+    }
+    if (J.useFg) {
+      L.mask.resize(n * J.S);
+      if (compute) {
+        L.bg.resize(n * J.D);
+      }
+    }
+    for (int s = 0; s < J.S; ++s) {
+      if (compute) {
+        uint16_t* dst = L.color.data() + n * 3 * s;
+        const fs::path path = image_path(DerpJob::levelDir(F.s("color"), level), J.rigSrc[s].id, frameName);
+        B.add(pool, [=] { load_color_bgr16_into(path, dst, w, h); });
+      }
+      if (J.useFg) {
+        uint8_t* dst = L.mask.data() + n * s;
+        const fs::path path = image_path(DerpJob::levelDir(F.s("foreground_masks"), level), J.rigSrc[s].id, frameName);
+        B.add(pool, [=] {
+          int mw, mh;
+          const std::vector<uint8_t> m = load_mask(path, mw, mh);
+          CHECK_MSG(mw == w && mh == h, "mask size mismatch: " + path.string());
+          memcpy(dst, m.data(), m.size());
+        });
+      }
+    }
+    if (J.useFg && compute) {
+      for (int d = 0; d < J.D; ++d) {
+        float* dst = L.bg.data() + n * d;
+        const fs::path path = image_path(DerpJob::levelDir(F.s("background_disp"), level), J.rigDst[d].id,
+                                         F.s("background_frame"));
+        B.add(pool, [=] {
+          int bw, bh;
+          const std::vector<float> bg = load_float(path, bw, bh);
+          CHECK_MSG(bw == w && bh == h, "background disparity size mismatch: " + path.string());
+          memcpy(dst, bg.data(), bg.size() * 4);
+        });
+      }
+    }
+    if (!compute) {  // resume: previous level from disk (DerpCLI.cpp:287-288)
+      L.prev.resize(n * J.D);
+      for (int d = 0; d < J.D; ++d) {
+        float* dst = L.prev.data() + n * d;
+        const fs::path path = image_path(DerpJob::levelDir(J.dispLevels, level), J.rigDst[d].id, frameName, ".pfm");
+        B.add(pool, [=] {
+          int pw, ph;
+          const std::vector<float> prev = load_float(path, pw, ph);
+          CHECK_MSG(pw == w && ph == h, "previous-level disparity size mismatch: " + path.string());
+          memcpy(dst, prev.data(), prev.size() * 4);
+        });
+      }
+    }
+  }
+
+  void wait(int k, int level) {
+    Timer t;
+    data[k][level].batch->wait();
+    waited += t.s();
+  }
+
+  // The decoded level becomes the sequence driver's input for (frame, level). The images were decoded into
+  // pageable memory (decoding starts before the HIP runtime exists, and a long sequence must not pin the host's
+  // RAM), from which uploads run at ~3 GB/s. With the frame resident in HBM the large levels therefore go through
+  // a small ring of page-locked bounce planes: pool workers copy plane s + 1.. while plane s moves at the PCIe rate,
+  // on the library's copy stream, i.e. behind the compute of the frame before.
+  // Out of core the library streams from the (pageable) buffers itself, whenever the frame's level is needed.
+  static constexpr int kBounce = 4;
+  Arena bounce[kBounce];
+  IoBatch bounceReady[kBounce];
+  void hand_over(derp_seq* seq, int k, int level, bool resident) {
+    derp_ctx* ctx = J.ctx;
+    Level& L = data[k][level];
+    const size_t plane = J.npx(level) * 3;  // u16 elements of one camera's image
+    const bool ring = resident && !L.color.empty() && plane * sizeof(uint16_t) >= (4u << 20);
+    if (ring) {
+      auto stage = [&](int s) {
+        Arena& A = bounce[s % kBounce];
+        A.ensure(plane * sizeof(uint16_t));
+        void* dst = A.p;
+        const uint16_t* src = L.color.data() + plane * s;
+        bounceReady[s % kBounce].add(pool, [=] { memcpy(dst, src, plane * sizeof(uint16_t)); });
+      };
+      for (int s = 0; s < std::min(kBounce, J.S); ++s) {
+        stage(s);
+      }
+      for (int s = 0; s < J.S; ++s) {
+        bounceReady[s % kBounce].wait();
+        DERP_OK(ctx, derp_seq_upload_color_plane(seq, frames[k], level, s, static_cast<const uint16_t*>(bounce[s % kBounce].p)));
+        if (s + kBounce < J.S) {
+          stage(s + kBounce);
+        }
+      }
+    }
+    if ((!ring && !L.color.empty()) || !L.mask.empty()) {
+      DERP_OK(ctx, derp_seq_host_inputs(seq, frames[k], level, ring || L.color.empty() ? nullptr : L.color.data(),
+                                        L.mask.empty() ? nullptr : L.mask.data(), L.bg.empty() ? nullptr : L.bg.data()));
+    }
+    if (!L.prev.empty()) {
+      for (int d = 0; d < J.D; ++d) {
+        DERP_OK(ctx, derp_seq_upload_disparity(seq, frames[k], level, d, L.prev.data() + J.npx(level) * d));
+      }
+    }
+  }
+};
+
 // saveResults (PyramidLevel.h:487-529): the selected frame's level is downloaded into page-locked memory and
 // written by the pool (PFM always, PNG on request) into every directory of `dirs`.
 struct LevelWriter {
@@ -393,7 +566,7 @@ struct LevelWriter {
   void save(int parity, size_t offset, int level, const std::string& frameName, const std::vector<fs::path>& dirs) {
     derp_ctx* ctx = J.ctx;
     const int w = J.W[level], h = J.H[level];
-    const bool png = J.savePng;
+    const bool png = J.savePng, exr = J.saveExr;
     for (int d = 0; d < J.D; ++d) {
       float* disp = reinterpret_cast<float*>(static_cast<char*>(arena[parity].p) + offset) + J.npx(level) * d;
       {
@@ -410,6 +583,39 @@ struct LevelWriter {
           write_pfm(base / (frameName + ".pfm"), disp, w, h);
           if (png) {
             write_disparity_png(base / (frameName + ".png"), disp, w, h);
+          }
+          if (exr) {
+            write_exr_f32(base / (frameName + ".exr"), disp, w, h);
+          }
+        }
+      });
+    }
+  }
+  // a sequence frame's level (resident slot or out-of-core host store) instead of the selected frame's
+  void save_seq(derp_seq* seq, int frame, int parity, size_t offset, int level, const std::string& frameName,
+                const std::vector<fs::path>& dirs, bool pngToo) {
+    derp_ctx* ctx = J.ctx;
+    const int w = J.W[level], h = J.H[level];
+    const bool png = J.savePng && pngToo, exr = J.saveExr && pngToo;
+    for (int d = 0; d < J.D; ++d) {
+      float* disp = reinterpret_cast<float*>(static_cast<char*>(arena[parity].p) + offset) + J.npx(level) * d;
+      {
+        Timer t;
+        DERP_OK(ctx, derp_seq_download_disparity(seq, frame, level, d, disp));
+        downloading += t.s();
+      }
+      std::vector<fs::path> bases;
+      for (const auto& dir : dirs) {
+        bases.push_back(DerpJob::levelDir(dir, level) / J.rigDst[d].id);
+      }
+      batch[parity].add(pool, [=] {
+        for (const auto& base : bases) {
+          write_pfm(base / (frameName + ".pfm"), disp, w, h);
+          if (png) {
+            write_disparity_png(base / (frameName + ".png"), disp, w, h);
+          }
+          if (exr) {
+            write_exr_f32(base / (frameName + ".exr"), disp, w, h);
           }
         }
       });

@@ -95,6 +95,8 @@ struct AreaTabDev {  // computeResizeAreaTab of one axis, resident in HBM
 struct derp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copyStream = nullptr;  // input uploads of a frame that is not being computed (sequence driver), with
+  DevBuf copyStaging;                // their own staging buffer: they overlap the compute of the frame before
   std::string err;
   derp_options opt;
   int S = 0, D = 0;
@@ -960,6 +962,9 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
     if (c->stream) {
       (void)hipStreamDestroy(c->stream);
     }
+    if (c->copyStream) {
+      (void)hipStreamDestroy(c->copyStream);
+    }
     delete c;
     return 1;
   };
@@ -987,7 +992,8 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
   if (const char* e = getenv("DERP_XCD_ROTATE")) {
     c->xcdRotate = atoi(e);
   }
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking) != hipSuccess) {
     return bail("hipStreamCreate failed");
   }
   c->S = n_src;
@@ -1190,6 +1196,18 @@ void* derp_host_alloc(size_t bytes) {
 void derp_host_free(void* p) {
   if (p) {
     (void)hipHostFree(p);
+  }
+}
+int derp_host_register(void* p, size_t bytes) {
+  if (!p || bytes == 0 || hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return 1;
+  }
+  return 0;
+}
+void derp_host_unregister(void* p) {
+  if (p && hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
   }
 }
 

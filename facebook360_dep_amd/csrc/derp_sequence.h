@@ -16,6 +16,14 @@
 // FILTERED level L+1, which needs raw level L+1 of frames t +- R, which ... — the dependency cone widens
 // by R frames per level, so every frame must finish level L before any frame starts level L-1.
 //
+// Out of core (derp_seq_options.resident_frames = N < owned frames): only N frame slots live in HBM. The inputs of
+// every owned frame stay in caller-owned host memory (derp_seq_host_inputs), the results in page-locked host
+// buffers of the library, and a level runs as  compute every frame (stream in colour L + the filtered level L+1,
+// processLevel, stream the raw level out)  ->  exchange  ->  filter every frame over a sliding window of slots.
+// The reference reaches the same independence from sequence length by round-tripping every level through the
+// file system (render.py:169-175, pipeline.py:120-171,364-408). Same kernels on the same data: results are
+// bit-identical to the resident mode.
+//
 // Transports: RCCL ncclSend/ncclRecv on the context's own stream (librccl is dlopen-ed on first use;
 // no torch in the loop), same-process loopback (several ranks emulated on one GPU: tests), or external
 // (the caller moves the buffers derp_seq_buffer names: torch.distributed / gloo tests).
@@ -142,6 +150,28 @@ struct derp_seq {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> exchangeSpans;
   double exchangeMs = 0;
   int levelReady = -1;                          // level whose compute finished and whose filter has not run yet
+  int levelExchanged = -1;                      // level whose halo disparities have arrived (exchange ran / was marked)
+  int computeLevel = -1, computedFrames = 0;    // progress of derp_seq_level_compute_frame over the owned frames
+  // ---- out-of-core mode (resident_frames < owned frames)
+  bool streaming = false;
+  int nSlots = 0;
+  struct HostIn {
+    const uint16_t* color = nullptr;            // [S][n][3] interleaved BGR u16 (what derp_upload_color takes)
+    const uint8_t* fg = nullptr;                // [S][n]
+    const float* bg = nullptr;                  // [D][n]
+  };
+  std::vector<std::vector<HostIn>> hostIn;      // [owned index][level], caller-owned memory
+  std::vector<std::vector<float*>> hostDisp;    // [owned index][level]: page-locked [D][n], the level's RESULT
+  std::vector<char> hostHave;                   // [owned index * numLevels + level]
+  std::vector<float*> hostRaw;                  // [owned index]: page-locked [D][nmax], raw level between compute and filter
+  struct SlotTag {
+    int k = -1, colorLevel = -1, rawLevel = -1; // what a device slot holds right now
+  };
+  std::vector<SlotTag> slotTag;
+  std::vector<int> edge;                        // owned frames some other rank's window reaches into (ascending)
+  std::vector<std::vector<DevBuf>> edgeColor, edgeFg;  // [edge index][level]
+  std::vector<DevBuf> edgeRaw;                  // [edge index]: raw level disparity [D][nmax]
+  std::vector<char> edgeStaged;                 // [level]: the edge frames' inputs of the level are in their device buffers
 };
 
 namespace {
@@ -153,6 +183,10 @@ int owned_index(const derp_seq* q, int frame) {
 int halo_index(const derp_seq* q, int frame) {
   auto it = std::lower_bound(q->halo.begin(), q->halo.end(), frame);
   return it != q->halo.end() && *it == frame ? (int)(it - q->halo.begin()) : -1;
+}
+int edge_index(const derp_seq* q, int frame) {
+  auto it = std::lower_bound(q->edge.begin(), q->edge.end(), frame);
+  return it != q->edge.end() && *it == frame ? (int)(it - q->edge.begin()) : -1;
 }
 
 // pyramid buffers of a frame slot whether it is selected or parked
@@ -179,7 +213,18 @@ int seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, size_t* 
   const size_t sz = kind == 0 ? n * c->S * sizeof(ushort4) : kind == 1 ? n * c->S : n * c->D * sizeof(float);
   DevBuf* b = nullptr;
   const int oi = owned_index(q, frame);
-  if (oi >= 0) {
+  if (oi >= 0 && q->streaming) {
+    // out of core: an owned frame has device buffers of its own only if another rank needs it
+    const int ei = edge_index(q, frame);
+    if (ei < 0) {
+      return fail(c, "frame %d streams through the frame slots (resident_frames = %d) and is in no other rank's window: "
+                     "it has no fixed device buffer", frame, q->nSlots);
+    }
+    b = kind == 0 ? &q->edgeColor[ei][level] : kind == 1 ? &q->edgeFg[ei][level] : &q->edgeRaw[ei];
+    if (b->bytes < sz) {
+      return fail(c, "edge buffer of frame %d level %d kind %d was not allocated", frame, level, kind);
+    }
+  } else if (oi >= 0) {
     SlotView v = slot_view(c, oi);
     b = kind == 0 ? &(*v.color)[level] : kind == 1 ? &(*v.fg)[level] : &(*v.disp)[level];
   } else {
@@ -242,6 +287,8 @@ int seq_exchange_rccl(derp_seq* q, int level, int kind) {
   return rc;
 }
 
+int seq_stage_edges(derp_seq* q, int level);
+
 // loopback: pull from the peer contexts of this process
 int seq_exchange_loopback(derp_seq* q, int level, int kind) {
   derp_ctx* c = q->c;
@@ -258,6 +305,9 @@ int seq_exchange_loopback(derp_seq* q, int level, int kind) {
     }
     derp_seq* peer = q->peers[tr.from_rank];
     if (!synced[tr.from_rank]) {
+      if (kind != 2 && seq_stage_edges(peer, level)) {  // an out-of-core peer stages the inputs it is asked for
+        return fail(c, "loopback peer %d: %s", tr.from_rank, peer->c->err.c_str());
+      }
       HIPCHK(c, hipStreamSynchronize(peer->c->stream));
       synced[tr.from_rank] = 1;
     }
@@ -331,6 +381,7 @@ void derp_seq_options_default(derp_seq_options* o) {
   o->use_foreground_masks = 0;  // pipeline.py:386 do_temporal_masking
   o->partition = DERP_SEQ_BLOCK;
   o->do_temporal_filter = 1;  // pipeline.py:378
+  o->resident_frames = 0;     // every owned frame resident in HBM
 }
 
 void derp_seq_window(int frame, int first, int last, int time_radius, int* lo, int* hi) {
@@ -420,7 +471,14 @@ int derp_seq_create(derp_seq** out, derp_ctx* c, int first, int last, int rank, 
   if (hipSetDevice(c->device) != hipSuccess) {
     return bail(fail(c, "hipSetDevice failed"));
   }
-  if (derp_set_frame_slots(c, std::max<int>(1, (int)q->owned.size()))) {
+  const int nOwned = (int)q->owned.size();
+  q->streaming = q->opt.resident_frames > 0 && q->opt.resident_frames < nOwned;
+  q->nSlots = q->streaming ? q->opt.resident_frames : std::max(1, nOwned);
+  if (q->streaming && q->opt.do_temporal_filter && q->nSlots < 2 * q->opt.time_radius + 1) {
+    return bail(fail(c, "resident_frames %d is smaller than the temporal window (2 * time_radius + 1 = %d frames)",
+                     q->nSlots, 2 * q->opt.time_radius + 1));
+  }
+  if (derp_set_frame_slots(c, q->nSlots)) {
     return bail(1);
   }
   const int nl = c->numLevels;
@@ -441,10 +499,50 @@ int derp_seq_create(derp_seq** out, derp_ctx* c, int first, int last, int rank, 
       }
     }
   }
-  q->filtered.resize(q->owned.size());
+  q->filtered.resize(q->streaming ? 1 : q->owned.size());  // out of core: one frame is filtered, then streamed out
   for (auto& b : q->filtered) {
     if (b.ensure(nmax * c->D * sizeof(float))) {
       return bail(fail(c, "out of device memory allocating the filtered level"));
+    }
+  }
+  if (q->streaming) {
+    q->slotTag.assign(q->nSlots, derp_seq::SlotTag());
+    q->hostIn.assign(nOwned, std::vector<derp_seq::HostIn>(nl));
+    q->hostDisp.assign(nOwned, std::vector<float*>(nl, nullptr));
+    q->hostHave.assign((size_t)nOwned * nl, 0);
+    q->hostRaw.assign(nOwned, nullptr);
+    for (int k = 0; k < nOwned; ++k) {
+      if (q->opt.do_temporal_filter && hipHostMalloc((void**)&q->hostRaw[k], nmax * c->D * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+        q->hostRaw[k] = nullptr;
+        return bail(fail(c, "out of page-locked host memory for the raw level of frame %d", q->owned[k]));
+      }
+      for (int l = 0; l < nl; ++l) {
+        const size_t n = npx(c, l);
+        if (n && hipHostMalloc((void**)&q->hostDisp[k][l], n * c->D * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+          q->hostDisp[k][l] = nullptr;
+          return bail(fail(c, "out of page-locked host memory for the results of frame %d", q->owned[k]));
+        }
+      }
+    }
+    for (const derp_seq_transfer& tr : q->plan) {  // frames this rank sends: they need fixed device buffers
+      if (tr.from_rank == rank && (q->edge.empty() || q->edge.back() != tr.frame)) {
+        q->edge.push_back(tr.frame);
+      }
+    }
+    q->edgeColor.assign(q->edge.size(), std::vector<DevBuf>(nl));
+    q->edgeFg.assign(q->edge.size(), std::vector<DevBuf>(nl));
+    q->edgeRaw.resize(q->edge.size());
+    for (size_t e = 0; e < q->edge.size(); ++e) {
+      if (q->edgeRaw[e].ensure(nmax * c->D * sizeof(float))) {
+        return bail(fail(c, "out of device memory allocating the edge frames"));
+      }
+      for (int l = 0; l < nl; ++l) {
+        const size_t n = npx(c, l);
+        if (n && (q->edgeColor[e][l].ensure(n * c->S * sizeof(ushort4)) ||
+                  (q->opt.use_foreground_masks && q->edgeFg[e][l].ensure(n * c->S)))) {
+          return bail(fail(c, "out of device memory allocating the edge frames"));
+        }
+      }
     }
   }
   if (q->fov.ensure(nmax * c->D) ||
@@ -479,6 +577,28 @@ void derp_seq_destroy(derp_seq* q) {
   }
   q->fov.release();
   q->winMask.release();
+  for (auto& v : q->hostDisp) {
+    for (float* p : v) {
+      if (p) {
+        (void)hipHostFree(p);
+      }
+    }
+  }
+  for (float* p : q->hostRaw) {
+    if (p) {
+      (void)hipHostFree(p);
+    }
+  }
+  for (auto* vv : {&q->edgeColor, &q->edgeFg}) {
+    for (auto& v : *vv) {
+      for (auto& b : v) {
+        b.release();
+      }
+    }
+  }
+  for (auto& b : q->edgeRaw) {
+    b.release();
+  }
   delete q;
 }
 
@@ -549,6 +669,10 @@ int derp_seq_attach_rccl(derp_seq* q, const void* unique_id, size_t bytes) {
   HIPCHK(c, hipSetDevice(c->device));
   ncclUniqueId id;
   memcpy(&id, unique_id, sizeof id);
+  if (q->comm) {  // re-attached: the previous communicator is not leaked
+    (void)api->CommDestroy(q->comm);
+    q->comm = nullptr;
+  }
   NCCLCHK(c, api, api->CommInitRank(&q->comm, q->world, id, q->rank));
   q->transport = SEQ_RCCL;
   return 0;
@@ -610,20 +734,368 @@ int derp_seq_selftest(derp_seq* q, int words) {
   return rc;
 }
 
-int derp_seq_exchange_inputs(derp_seq* q) {
+// ---- out-of-core helpers ------------------------------------------------------------------------
+}  // extern "C"
+namespace {
+
+// BGR u16 host plane -> BGRX texels of `dst` plane s (what derp_upload_color does for the selected slot)
+int upload_color_plane(derp_ctx* c, DevBuf& dst, int s, const uint16_t* bgr, size_t n) {
+  TRY(upload_tmp(c, c->staging, bgr, n * 3));
+  hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->stream, c->staging.as<uint16_t>(),
+                     dst.as<ushort4>() + (size_t)s * n, n);
+  KCHECK(c);
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the staging buffer is reused by the next plane
+  return 0;
+}
+
+int host_inputs_of(derp_seq* q, int k, int level, const derp_seq::HostIn** out) {
+  const derp_seq::HostIn& h = q->hostIn[k][level];
+  if (!h.color && !h.fg) {
+    return fail(q->c, "frame %d level %d: no host inputs registered (derp_seq_host_inputs)", q->owned[k], level);
+  }
+  *out = &h;
+  return 0;
+}
+
+// out of core: inputs of the frames other ranks' windows reach into -> their fixed device buffers (once per level)
+int seq_stage_edges(derp_seq* q, int level) {
+  derp_ctx* c = q->c;
+  if (!q->streaming || q->edge.empty()) {
+    return 0;
+  }
+  if (q->edgeStaged.empty()) {
+    q->edgeStaged.assign(c->numLevels, 0);
+  }
+  if (q->edgeStaged[level]) {
+    return 0;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = npx(c, level);
+  for (size_t e = 0; e < q->edge.size(); ++e) {
+    const derp_seq::HostIn* h;
+    TRY(host_inputs_of(q, owned_index(q, q->edge[e]), level, &h));
+    if (!h->color) {
+      return fail(c, "frame %d level %d: only masks were registered, the colour images are needed", q->edge[e], level);
+    }
+    for (int s = 0; s < c->S; ++s) {
+      TRY(upload_color_plane(c, q->edgeColor[e][level], s, h->color + (size_t)s * n * 3, n));
+    }
+    if (q->opt.use_foreground_masks) {
+      if (!h->fg) {
+        return fail(c, "frame %d level %d: temporal masking needs the foreground masks", q->edge[e], level);
+      }
+      HIPCHK(c, hipMemcpy(q->edgeFg[e][level].p, h->fg, n * c->S, hipMemcpyHostToDevice));
+    }
+  }
+  q->edgeStaged[level] = 1;
+  return 0;
+}
+
+// colour (+ masks, background) of `level` of owned frame k into the SELECTED slot
+int stream_in_level(derp_seq* q, int k, int level, bool forCompute) {
+  derp_ctx* c = q->c;
+  const derp_seq::HostIn* h;
+  TRY(host_inputs_of(q, k, level, &h));
+  if (!h->color) {
+    return fail(c, "frame %d level %d: only masks were registered, the colour images are needed", q->owned[k], level);
+  }
+  const size_t n = npx(c, level);
+  for (int s = 0; s < c->S; ++s) {
+    TRY(upload_color_plane(c, c->pyrColor[level], s, h->color + (size_t)s * n * 3, n));
+  }
+  if (h->fg) {
+    HIPCHK(c, hipMemcpy(c->pyrFg[level].p, h->fg, n * c->S, hipMemcpyHostToDevice));
+  }
+  if (forCompute && h->bg) {
+    HIPCHK(c, hipMemcpy(c->pyrBg[level].p, h->bg, n * c->D * sizeof(float), hipMemcpyHostToDevice));
+    c->haveBg[level] = 1;
+  }
+  return 0;
+}
+
+// processLevel(level) of owned frame k in out-of-core mode: stream in, compute, stream the raw level out
+int stream_compute_frame(derp_seq* q, int level, int k) {
+  derp_ctx* c = q->c;
+  const int slot = k % q->nSlots;
+  TRY(select_frame(c, slot));
+  derp_seq::SlotTag& tag = q->slotTag[slot];
+  if (tag.k != k || tag.colorLevel != level) {
+    tag = derp_seq::SlotTag();
+    TRY(stream_in_level(q, k, level, true));
+  }
+  const int up = level + 1;
+  const bool seeded = up < c->numLevels && npx(c, up) != 0;
+  if (seeded) {
+    if (!q->hostHave[(size_t)k * c->numLevels + up]) {
+      return fail(c, "Missing disparity of level %d needed to start level %d (frame %d)", up, level, q->owned[k]);
+    }
+    HIPCHK(c, hipMemcpy(c->pyrDisp[up].p, q->hostDisp[k][up], npx(c, up) * c->D * sizeof(float), hipMemcpyHostToDevice));
+    c->haveDisp[up] = 1;
+    if (c->opt.use_foreground_masks) {  // the masked upsample reads the coarse mask too (DerpCLI.cpp:280-285)
+      const derp_seq::HostIn* hu;
+      TRY(host_inputs_of(q, k, up, &hu));
+      if (hu->fg) {
+        HIPCHK(c, hipMemcpy(c->pyrFg[up].p, hu->fg, npx(c, up) * c->S, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  TRY(process_level(c, level));
+  const size_t bytes = npx(c, level) * c->D * sizeof(float);
+  float* out = q->opt.do_temporal_filter ? q->hostRaw[k] : q->hostDisp[k][level];
+  HIPCHK(c, hipMemcpyAsync(out, c->pyrDisp[level].p, bytes, hipMemcpyDeviceToHost, c->stream));
+  const int ei = edge_index(q, q->owned[k]);
+  if (ei >= 0) {
+    HIPCHK(c, hipMemcpyAsync(q->edgeRaw[ei].p, c->pyrDisp[level].p, bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  tag.k = k;
+  tag.colorLevel = tag.rawLevel = level;
+  if (!q->opt.do_temporal_filter) {
+    q->hostHave[(size_t)k * c->numLevels + level] = 1;
+  }
+  return 0;
+}
+
+// temporal filter of every owned frame in out-of-core mode: a sliding window of slots holds (colour L, raw L)
+int stream_filter_level(derp_seq* q, int level, int W, int H, int radius) {
+  derp_ctx* c = q->c;
+  const size_t n = (size_t)W * H;
+  for (int j = 0; j < (int)q->owned.size(); ++j) {
+    const int t = q->owned[j];
+    int lo, hi;
+    seq_window(t, q->first, q->last, q->opt.time_radius, &lo, &hi);
+    TemporalFrames F;
+    F.n = hi - lo + 1;
+    for (int u = lo; u <= hi; ++u) {
+      const void *pc, *pd, *pm;
+      const int ku = owned_index(q, u);
+      if (ku >= 0) {
+        const int slot = ku % q->nSlots;
+        derp_seq::SlotTag& tag = q->slotTag[slot];
+        if (tag.k != ku || tag.colorLevel != level || tag.rawLevel != level) {
+          TRY(select_frame(c, slot));
+          if (tag.k != ku || tag.colorLevel != level) {
+            tag = derp_seq::SlotTag();
+            TRY(stream_in_level(q, ku, level, false));
+          }
+          HIPCHK(c, hipMemcpy(c->pyrDisp[level].p, q->hostRaw[ku], n * c->D * sizeof(float), hipMemcpyHostToDevice));
+          tag.k = ku;
+          tag.colorLevel = tag.rawLevel = level;
+        }
+        SlotView v = slot_view(c, slot);
+        pc = (*v.color)[level].p;
+        pd = (*v.disp)[level].p;
+        pm = (*v.fg)[level].p;
+      } else {
+        void* p;
+        size_t b;
+        TRY(seq_buffer(q, u, level, 0, &p, &b));
+        pc = p;
+        TRY(seq_buffer(q, u, level, 2, &p, &b));
+        pd = p;
+        pm = nullptr;
+        if (q->opt.use_foreground_masks) {
+          TRY(seq_buffer(q, u, level, 1, &p, &b));
+          pm = p;
+        }
+      }
+      if (q->opt.use_foreground_masks) {  // mask = fg & fov of each frame (TemporalBilateralFilter.cpp:150-160)
+        uint8_t* wm = q->winMask.as<uint8_t>() + (size_t)(u - lo) * n * c->D;
+        hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), c->D), dim3(256), 0, c->stream, q->fov.as<uint8_t>(),
+                           (const uint8_t*)pm, c->dst2src.as<int>(), 0, n, wm);
+        KCHECK(c);
+        pm = wm;
+      } else {
+        pm = q->fov.p;
+      }
+      F.guides[u - lo] = reinterpret_cast<const ushort4*>(pc);
+      F.images[u - lo] = reinterpret_cast<const float*>(pd);
+      F.masks[u - lo] = reinterpret_cast<const uint8_t*>(pm);
+    }
+    hipLaunchKernelGGL(k_temporal, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, F, W, H, t - lo, q->opt.sigma,
+                       radius, q->opt.weight_b, q->opt.weight_g, q->opt.weight_b, q->filtered[0].as<float>(),
+                       c->dst2src.as<int>());
+    KCHECK(c);
+    // "Transfer": the filtered level is the frame's result; the raw levels stay untouched in hostRaw
+    HIPCHK(c, hipMemcpyAsync(q->hostDisp[j][level], q->filtered[0].p, n * c->D * sizeof(float), hipMemcpyDeviceToHost,
+                             c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    q->hostHave[(size_t)j * c->numLevels + level] = 1;
+  }
+  return 0;
+}
+
+}  // namespace
+extern "C" {
+
+int derp_seq_host_inputs(derp_seq* q, int frame, int level, const uint16_t* color_bgr, const uint8_t* fg_masks,
+                         const float* background_disparity) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0 || (!color_bgr && !fg_masks)) {  // masks alone: a level that only feeds the masked upsample
+    return fail(c, k < 0 ? "frame %d is not owned by rank %d" : "frame %d: neither colour nor masks", frame, q->rank);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  if (q->streaming) {
+    q->hostIn[k][level] = {color_bgr, fg_masks, background_disparity};
+    if (!q->edgeStaged.empty() && edge_index(q, frame) >= 0) {
+      q->edgeStaged[level] = 0;
+    }
+    for (derp_seq::SlotTag& tag : q->slotTag) {  // a slot holding an older version of these inputs is stale
+      if (tag.k == k && tag.colorLevel == level) {
+        tag = derp_seq::SlotTag();
+      }
+    }
+    return 0;
+  }
+  const size_t n = npx(c, level);
+  TRY(select_frame(c, k));
+  for (int s = 0; color_bgr && s < c->S; ++s) {
+    TRY(upload_color_plane(c, c->pyrColor[level], s, color_bgr + (size_t)s * n * 3, n));
+  }
+  if (fg_masks) {
+    HIPCHK(c, hipMemcpy(c->pyrFg[level].p, fg_masks, n * c->S, hipMemcpyHostToDevice));
+  }
+  if (background_disparity) {
+    HIPCHK(c, hipMemcpy(c->pyrBg[level].p, background_disparity, n * c->D * sizeof(float), hipMemcpyHostToDevice));
+    c->haveBg[level] = 1;
+  }
+  return 0;
+}
+
+int derp_seq_upload_color_plane(derp_seq* q, int frame, int level, int s, const uint16_t* bgr) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0 || s < 0 || s >= c->S || !bgr) {
+    return fail(c, "bad frame / source index / null image");
+  }
+  if (q->streaming) {
+    return fail(c, "out of core the frames stream from the buffers given to derp_seq_host_inputs");
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  // on the copy stream, into the frame's own slot: the frame computing on the main stream is another one
+  const size_t n = npx(c, level);
+  SlotView v = slot_view(c, k);
+  ALLOC(c, c->copyStaging, n * 3 * sizeof(uint16_t));
+  HIPCHK(c, hipMemcpyAsync(c->copyStaging.p, bgr, n * 3 * sizeof(uint16_t), hipMemcpyHostToDevice, c->copyStream));
+  hipLaunchKernelGGL(k_bgr_to_bgrx, dim3(flat_grid(n)), dim3(256), 0, c->copyStream, c->copyStaging.as<uint16_t>(),
+                     (*v.color)[level].as<ushort4>() + (size_t)s * n, n);
+  KCHECK(c);
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));  // the staging buffer and `bgr` are free again
+  return 0;
+}
+
+int derp_seq_upload_disparity(derp_seq* q, int frame, int level, int d, const float* disp) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0 || d < 0 || d >= c->D || !disp) {
+    return fail(c, "bad frame / destination index / null image");
+  }
+  if (q->streaming) {
+    memcpy(q->hostDisp[k][level] + (size_t)d * npx(c, level), disp, npx(c, level) * sizeof(float));
+    q->hostHave[(size_t)k * c->numLevels + level] = 1;
+    return 0;
+  }
+  TRY(select_frame(c, k));
+  return derp_upload_disparity(c, level, d, disp);
+}
+
+int derp_seq_download_disparity(derp_seq* q, int frame, int level, int d, float* disp) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0 || d < 0 || d >= c->D || !disp) {
+    return fail(c, "bad frame / destination index / null output");
+  }
+  if (q->streaming) {
+    if (!q->hostHave[(size_t)k * c->numLevels + level]) {
+      return fail(c, "level %d of frame %d has not been processed", level, frame);
+    }
+    memcpy(disp, q->hostDisp[k][level] + (size_t)d * npx(c, level), npx(c, level) * sizeof(float));
+    return 0;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  TRY(select_frame(c, k));
+  return derp_download_disparity(c, level, d, disp);
+}
+
+int derp_seq_exchange_inputs_level(derp_seq* q, int level) {
   if (!q) {
     return 1;
   }
   derp_ctx* c = q->c;
   HIPCHK(c, hipSetDevice(c->device));
+  TRY(check_level(c, level));
+  TRY(seq_stage_edges(q, level));  // out of core: the frames other ranks read, into their fixed device buffers
+  TRY(seq_exchange(q, level, 0));
+  if (q->opt.use_foreground_masks) {
+    TRY(seq_exchange(q, level, 1));
+  }
+  return 0;
+}
+
+int derp_seq_exchange_inputs(derp_seq* q) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
   for (int l = 0; l < c->numLevels; ++l) {
     if (npx(c, l) == 0) {
       continue;
     }
-    TRY(seq_exchange(q, l, 0));
-    if (q->opt.use_foreground_masks) {
-      TRY(seq_exchange(q, l, 1));
+    TRY(derp_seq_exchange_inputs_level(q, l));
+  }
+  return 0;
+}
+
+int derp_seq_level_compute_frame(derp_seq* q, int level, int frame) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  const int k = owned_index(q, frame);
+  if (k < 0) {
+    return fail(c, "frame %d is not owned by rank %d", frame, q->rank);
+  }
+  if (q->computeLevel != level) {
+    q->computeLevel = level;
+    q->computedFrames = 0;
+    q->levelReady = -1;
+  }
+  // the projection warps depend on the rig and the level size only (precomputeProjections, Derp.cpp:955-976):
+  // the first frame of the level builds them (always, when rebuild_warp_tables asks for the reference's
+  // per-invocation rebuild), the other frames of the level reuse them
+  const int rebuild = c->opt.rebuild_warp_tables;
+  c->opt.rebuild_warp_tables = q->computedFrames == 0 ? rebuild : 0;
+  int rc;
+  if (q->streaming) {
+    rc = stream_compute_frame(q, level, k);
+  } else {
+    rc = select_frame(c, k);
+    if (!rc) {
+      rc = process_level(c, level);
     }
+  }
+  c->opt.rebuild_warp_tables = rebuild;
+  TRY(rc);
+  if (++q->computedFrames >= (int)q->owned.size()) {
+    q->levelReady = level;
   }
   return 0;
 }
@@ -632,23 +1104,13 @@ int derp_seq_level_compute(derp_seq* q, int level) {
   if (!q) {
     return 1;
   }
-  derp_ctx* c = q->c;
-  HIPCHK(c, hipSetDevice(c->device));
-  // the projection warps depend on the rig and the level size only (precomputeProjections, Derp.cpp:955-976):
-  // the first frame of the level builds them (always, when rebuild_warp_tables asks for the reference's
-  // per-invocation rebuild), the other frames of the level reuse them
-  const int rebuild = c->opt.rebuild_warp_tables;
-  int rc = 0;
-  for (int k = 0; k < (int)q->owned.size() && !rc; ++k) {
-    rc = select_frame(c, k);
-    if (!rc) {
-      c->opt.rebuild_warp_tables = k == 0 ? rebuild : 0;
-      rc = process_level(c, level);
-    }
+  q->computeLevel = -1;  // a fresh pass over the level
+  for (int t : q->owned) {
+    TRY(derp_seq_level_compute_frame(q, level, t));
   }
-  c->opt.rebuild_warp_tables = rebuild;
-  TRY(rc);
-  q->levelReady = level;
+  if (q->owned.empty()) {
+    q->levelReady = level;
+  }
   return 0;
 }
 
@@ -661,7 +1123,22 @@ int derp_seq_level_exchange(derp_seq* q, int level) {
   if (!q->opt.do_temporal_filter) {
     return 0;
   }
-  return seq_exchange(q, level, 2);
+  if (q->levelReady != level) {
+    return fail(c, "derp_seq_level_exchange(%d): derp_seq_level_compute(%d) has not completed for every owned frame", level, level);
+  }
+  TRY(seq_exchange(q, level, 2));
+  if (q->transport != SEQ_EXTERNAL) {
+    q->levelExchanged = level;
+  }
+  return 0;
+}
+
+int derp_seq_mark_exchanged(derp_seq* q, int level) {
+  if (!q) {
+    return 1;
+  }
+  q->levelExchanged = level;
+  return 0;
 }
 
 int derp_seq_level_filter(derp_seq* q, int level) {
@@ -674,6 +1151,14 @@ int derp_seq_level_filter(derp_seq* q, int level) {
   if (!q->opt.do_temporal_filter) {
     return 0;
   }
+  // the filter reads the raw level of every window frame: a skipped or reordered phase would filter stale data
+  if (q->levelReady != level) {
+    return fail(c, "derp_seq_level_filter(%d): derp_seq_level_compute(%d) has not completed for every owned frame", level, level);
+  }
+  if (!q->halo.empty() && q->levelExchanged != level) {
+    return fail(c, "derp_seq_level_filter(%d): the halo frames' level has not been exchanged (derp_seq_level_exchange, or "
+                   "derp_seq_mark_exchanged after an external transport moved it)", level);
+  }
   const int W = c->LW[level], H = c->LH[level];
   const size_t n = (size_t)W * H;
   Span sp(c, ST_TEMPORAL, level);  // masks + temporal kernels + write-back of every owned frame
@@ -681,6 +1166,11 @@ int derp_seq_level_filter(derp_seq* q, int level) {
                      q->fov.as<uint8_t>());
   KCHECK(c);
   const int radius = temporal_space_radius(q, level);
+  if (q->streaming) {
+    TRY(stream_filter_level(q, level, W, H, radius));
+    q->levelReady = -1;
+    return 0;
+  }
   for (int k = 0; k < (int)q->owned.size(); ++k) {
     const int t = q->owned[k];
     int lo, hi;

@@ -20,7 +20,7 @@ class SeqOptions(C.Structure):
     _fields_ = [
         ("time_radius", C.c_int32), ("sigma", C.c_float), ("weight_b", C.c_float), ("weight_g", C.c_float),
         ("weight_r", C.c_float), ("space_radius", C.c_int32), ("use_foreground_masks", C.c_int32),
-        ("partition", C.c_int32), ("do_temporal_filter", C.c_int32),
+        ("partition", C.c_int32), ("do_temporal_filter", C.c_int32), ("resident_frames", C.c_int32),
     ]
 
 
@@ -63,11 +63,13 @@ EXPORTS = [
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
     "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
-    "derp_set_frame_slots", "derp_select_frame", "derp_frame_slots", "derp_host_alloc", "derp_host_free",
+    "derp_set_frame_slots", "derp_select_frame", "derp_frame_slots", "derp_host_alloc", "derp_host_free", "derp_host_register", "derp_host_unregister",
     "derp_seq_options_default", "derp_seq_window", "derp_seq_owner", "derp_seq_plan", "derp_seq_create", "derp_seq_destroy",
     "derp_seq_counts", "derp_seq_frames", "derp_seq_frame_slot", "derp_seq_buffer", "derp_rccl_unique_id",
     "derp_seq_attach_rccl", "derp_seq_attach_loopback", "derp_seq_attach_external", "derp_seq_selftest",
     "derp_seq_exchange_inputs", "derp_seq_level_compute", "derp_seq_level_exchange", "derp_seq_level_filter",
+    "derp_seq_host_inputs", "derp_seq_upload_color_plane", "derp_seq_upload_disparity", "derp_seq_download_disparity", "derp_seq_exchange_inputs_level",
+    "derp_seq_level_compute_frame", "derp_seq_mark_exchanged",
     "derp_seq_run", "derp_seq_stats", "derp_seq_stats_reset",
 ]
 

@@ -35,6 +35,56 @@ def read_pfm(path):
     return np.frombuffer(data, dtype="<f4", count=w * h, offset=nl3 + 1).reshape(h, w).copy()
 
 
+def read_exr(path):
+    """Single-part scan-line OpenEXR with one FLOAT channel (what cv::imwrite writes for a CV_32FC1 disparity and
+    what this build's executables write for --output_formats=exr): NO / ZIPS / ZIP compression."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x76\x2f\x31\x01":
+        raise ValueError("not an OpenEXR file: %s" % path)
+    version, = struct.unpack_from("<I", data, 4)
+    if version & 0xFF != 2 or version & 0x1A00:  # tiled / multi-part / deep
+        raise ValueError("unsupported OpenEXR flavour %#x: %s" % (version, path))
+    pos, attrs = 8, {}
+    while data[pos] != 0:
+        e = data.index(b"\0", pos)
+        name = data[pos:e].decode()
+        e2 = data.index(b"\0", e + 1)
+        typ = data[e + 1:e2].decode()
+        size, = struct.unpack_from("<i", data, e2 + 1)
+        attrs[name] = (typ, data[e2 + 5:e2 + 5 + size])
+        pos = e2 + 5 + size
+    pos += 1
+    ch = attrs["channels"][1]
+    e = ch.index(b"\0")
+    ptype, = struct.unpack_from("<i", ch, e + 1)
+    if ch[e + 17:] != b"\0" or ptype != 2:
+        raise ValueError("expected exactly one FLOAT channel: %s" % path)
+    comp = attrs["compression"][1][0]
+    x0, y0, x1, y1 = struct.unpack("<4i", attrs["dataWindow"][1])
+    w, h = x1 - x0 + 1, y1 - y0 + 1
+    lines = {0: 1, 2: 1, 3: 16}.get(comp)
+    if lines is None:
+        raise ValueError("unsupported compression %d: %s" % (comp, path))
+    blocks = (h + lines - 1) // lines
+    offsets = struct.unpack_from("<%dQ" % blocks, data, pos)
+    out = np.empty((h, w), dtype=np.float32)
+    for off in offsets:
+        y, size = struct.unpack_from("<ii", data, off)
+        n = min(lines, y1 - y + 1)
+        raw = n * w * 4
+        buf = data[off + 8:off + 8 + size]
+        if comp != 0 and size < raw:
+            t = np.frombuffer(zlib.decompress(buf), dtype=np.uint8).astype(np.int64)
+            t = ((np.cumsum(t - 128) + 128) & 0xFF).astype(np.uint8)  # undo the predictor
+            half = (raw + 1) // 2
+            px = np.empty(raw, dtype=np.uint8)
+            px[0::2], px[1::2] = t[:half], t[half:]
+            buf = px.tobytes()
+        out[y - y0:y - y0 + n] = np.frombuffer(buf, dtype="<f4", count=n * w).reshape(n, w)
+    return out
+
+
 def _chunk(tag, payload):
     return struct.pack(">I", len(payload)) + tag + payload + struct.pack(">I", zlib.crc32(tag + payload) & 0xFFFFFFFF)
 

@@ -123,6 +123,7 @@ def run_schedule(backend, levels, first, last, rank, world, radius=2, partition=
             received += exchange(transfers, rank, lambda f: backend.tensor(f, level, KIND_DISPARITY), dist, mode,
                                  lambda: backend.scratch(level, KIND_DISPARITY))
             backend.after_exchange()
+            getattr(backend, "exchanged", lambda lv: None)(level)
         backend.filter(level)
     return received
 
@@ -155,6 +156,9 @@ class SequenceRunner:
         self._stage = False
         self._pending = []
         self._received = 0  # bytes moved by the external (torch.distributed) transports
+        # out of core (resident_frames < owned frames): inputs stay in host memory, kept alive here
+        self.streaming = 0 < self.opt.resident_frames < len(self.owned)
+        self._host = {}
 
     def _frames(self, halo, n):
         buf = (C.c_int * max(n, 1))()
@@ -180,16 +184,45 @@ class SequenceRunner:
         return derp.lib().derp_seq_frame_slot(self.h, frame)
 
     def upload_frame(self, frame, data):
-        """Upload `data` (synth.make_frame dict) as sequence frame `frame` (must be owned)."""
+        """Upload `data` (synth.make_frame dict) as sequence frame `frame` (must be owned). Out of core the
+        library streams from the host arrays level by level; they are kept alive by this object."""
+        import numpy as np
+
         s = self.slot(frame)
         if s < 0:
             raise ValueError("frame %d is not owned by rank %d" % (frame, self.rank))
-        self.g.select_frame(s)
-        self.g.upload_frame(data)
+        if not self.streaming:
+            self.g.select_frame(s)
+            self.g.upload_frame(data)
+            return
+
+        def arr(x):
+            return x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+
+        g = self.g
+        keep = []
+        for level in range(len(g.sizes)):
+            col = np.ascontiguousarray(np.stack([arr(data["color"][level][s]) for s in range(g.S)]), np.uint16)
+            fg = bg = None
+            if data.get("masks"):
+                fg = np.ascontiguousarray(np.stack([arr(data["masks"][level][s]) for s in range(g.S)]), np.uint8)
+            if data.get("bg_disp"):
+                bg = np.ascontiguousarray(np.stack([arr(data["bg_disp"][level][g._dst_src(d)]) for d in range(g.D)]),
+                                          np.float32)
+            keep.append((col, fg, bg))
+            self._ck(derp.lib().derp_seq_host_inputs(
+                self.h, frame, level, col.ctypes.data_as(C.c_void_p),
+                fg.ctypes.data_as(C.c_void_p) if fg is not None else None,
+                bg.ctypes.data_as(C.c_void_p) if bg is not None else None))
+        self._host[frame] = keep
 
     def download_disparity(self, frame, level, d):
-        self.g.select_frame(self.slot(frame))
-        return self.g.download_disparity(level, d)
+        import numpy as np
+
+        w, h = self.g.sizes[level]
+        out = np.zeros((h, w), dtype=np.float32)
+        self._ck(derp.lib().derp_seq_download_disparity(self.h, frame, level, d, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def result_crc(self, level=0):
         """{frame: CRC-32 of the frame's level-`level` disparity, destinations in rig order, float32 bytes with
@@ -312,6 +345,8 @@ class SequenceRunner:
             self.before_exchange()
             kinds = [KIND_COLOR] + ([KIND_FG] if self.opt.use_foreground_masks else [])
             for level in range(len(self.g.sizes)):
+                # with an external transport this moves nothing; out of core it stages the frames other ranks read
+                self._ck(derp.lib().derp_seq_exchange_inputs_level(self.h, level))
                 for kind in kinds:
                     exchange(transfers, self.rank, lambda f: self.tensor(f, level, kind), self._dist, self._mode,
                              lambda: self.scratch(level, kind))
@@ -324,6 +359,13 @@ class SequenceRunner:
 
     def exchange_level(self, level):
         self._ck(derp.lib().derp_seq_level_exchange(self.h, level))
+
+    def compute_frame(self, level, frame):
+        self._ck(derp.lib().derp_seq_level_compute_frame(self.h, level, frame))
+
+    def exchanged(self, level):
+        """An external transport (torch.distributed) has delivered the halo frames' level."""
+        self._ck(derp.lib().derp_seq_mark_exchanged(self.h, level))
 
     def filter(self, level):
         self._ck(derp.lib().derp_seq_level_filter(self.h, level))

@@ -189,18 +189,25 @@ def intersect(origin, d, shift):
     Returns (t, hit point in scene coordinates, is_plane, t of the background sphere alone)."""
     import torch
 
-    o = torch.tensor([origin[i] - shift[i] for i in range(3)], dtype=torch.float64, device=d.device)
-    b = (d * o).sum(-1)
-    c = float(o @ o) - SPHERE_R**2
+    # Scalars in Python floats and 3-term dot products written out element-wise: BLAS dot products and vectorised
+    # reductions round differently from one host CPU to the next, and the frames must not depend on the host.
+    ol = [float(origin[i]) - float(shift[i]) for i in range(3)]
+    o = torch.tensor(ol, dtype=torch.float64, device=d.device)
+
+    def dot3(v):
+        return d[..., 0] * v[0] + d[..., 1] * v[1] + d[..., 2] * v[2]
+
+    b = dot3(ol)
+    c = (ol[0] * ol[0] + ol[1] * ol[1] + ol[2] * ol[2]) - SPHERE_R**2
     tb = -b + torch.sqrt((b * b - c).clamp_min(0.0))
     t = tb.clone()
     is_plane = torch.zeros(t.shape, dtype=torch.bool, device=d.device)
     for n, cc, centre, half in PLANES:
-        n = torch.tensor(n, dtype=torch.float64, device=d.device)
+        on = ol[0] * n[0] + ol[1] * n[1] + ol[2] * n[2]
         centre = torch.tensor(centre, dtype=torch.float64, device=d.device)
-        denom = (d * n).sum(-1)
+        denom = dot3(n)
         denom = torch.where(denom.abs() > 1e-9, denom, torch.full_like(denom, 1e-9))
-        tp = (cc - float(o @ n)) / denom
+        tp = (cc - on) / denom
         hit = o + tp[..., None] * d
         inside = (tp > 0) & ((hit - centre).abs().amax(dim=-1) < half) & (tp < t)
         t = torch.where(inside, tp, t)

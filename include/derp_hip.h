@@ -100,6 +100,11 @@ int derp_frame_slots(const derp_ctx* ctx, int* n_slots, int* selected);
  * derp_host_alloc returns NULL on failure (callers fall back to malloc). */
 void* derp_host_alloc(size_t bytes);
 void derp_host_free(void* p);
+/* page-lock / release memory the caller allocated itself (image buffers decoded before the runtime was up):
+ * uploads from it then run at the PCIe rate. derp_host_register returns non-zero when the runtime refuses; the
+ * memory stays usable, only slower. */
+int derp_host_register(void* p, size_t bytes);
+void derp_host_unregister(void* p);
 
 /* ---- inputs (loadLevelImages, ImageUtil.h:79-94; DerpCLI.cpp:235-248,276-303) ------------ */
 int derp_upload_color(derp_ctx* ctx, int level, int src, const uint16_t* bgr);
@@ -265,6 +270,11 @@ typedef struct {
   int32_t use_foreground_masks; /* temporal masking (pipeline.py:386 do_temporal_masking) */
   int32_t partition;            /* DERP_SEQ_BLOCK | DERP_SEQ_CYCLIC */
   int32_t do_temporal_filter;   /* 0 = replicas: no window, no exchange (pipeline.py:378) */
+  int32_t resident_frames;      /* 0 = every owned frame lives in HBM; N < owned frames = out of core: N frame slots,
+                                 * inputs streamed per level from host memory (derp_seq_host_inputs), results kept in
+                                 * page-locked host buffers; N >= 2 * time_radius + 1. The reference is independent of
+                                 * the sequence length because every level round-trips through the file system
+                                 * (render.py:169-175, pipeline.py:120-171) */
 } derp_seq_options;
 typedef struct {
   int32_t frame, from_rank, to_rank;
@@ -284,6 +294,19 @@ void derp_seq_destroy(derp_seq* seq);
 int derp_seq_counts(const derp_seq* seq, int* n_owned, int* n_halo);
 int derp_seq_frames(const derp_seq* seq, int halo, int* frames, int cap);
 int derp_seq_frame_slot(const derp_seq* seq, int frame);   /* -1 when not owned by this rank */
+/* Inputs of one level of an owned frame from host memory — loadLevelImages (ImageUtil.h:79-94) for the frame:
+ * colour [S][h*w][3] interleaved BGR u16, optional foreground masks [S][h*w] u8 and background disparity
+ * [D][h*w] f32. Resident mode: uploaded into the frame's slot now. Out of core: the pointers are kept and must
+ * stay valid until the sequence is destroyed (or replaced by another call). */
+int derp_seq_host_inputs(derp_seq* seq, int frame, int level, const uint16_t* color_bgr, const uint8_t* fg_masks,
+                         const float* background_disparity);
+/* Resident mode: one camera's colour image [h*w][3] BGR u16 into the frame's slot on the library's copy stream —
+ * it overlaps whatever another frame is computing (the frame itself must not be in flight). */
+int derp_seq_upload_color_plane(derp_seq* seq, int frame, int level, int src, const uint16_t* bgr);
+/* level disparity of an owned frame, whichever mode: upload = the previous level read back from disk when a run
+ * resumes (DerpCLI.cpp:287-288); download = the level's result (filtered when the temporal filter is on) */
+int derp_seq_upload_disparity(derp_seq* seq, int frame, int level, int dst, const float* disparity);
+int derp_seq_download_disparity(derp_seq* seq, int frame, int level, int dst, float* disparity);
 /* buffer of an owned or halo frame: kind 0 colour [S][h*w] BGRX u16, 1 fg mask [S][h*w] u8,
  * 2 level disparity [D][h*w] f32 */
 int derp_seq_buffer(derp_seq* seq, int frame, int level, int kind, void** ptr, size_t* bytes);
@@ -295,9 +318,14 @@ int derp_seq_attach_external(derp_seq* seq);
 int derp_seq_selftest(derp_seq* seq, int words);           /* one ring step over RCCL, verified */
 /* schedule */
 int derp_seq_exchange_inputs(derp_seq* seq);               /* colour (+ fg) pyramids of the halo frames, once */
+int derp_seq_exchange_inputs_level(derp_seq* seq, int level);  /* ... one level of them (inputs that arrive level by level) */
 int derp_seq_level_compute(derp_seq* seq, int level);      /* processLevel(level) of every owned frame */
+int derp_seq_level_compute_frame(derp_seq* seq, int level, int frame);  /* ... of one owned frame (each once per level) */
 int derp_seq_level_exchange(derp_seq* seq, int level);     /* raw level disparity of the halo frames */
-int derp_seq_level_filter(derp_seq* seq, int level);       /* temporal filter of every owned frame + Transfer */
+int derp_seq_mark_exchanged(derp_seq* seq, int level);     /* external transport: the halo frames' level has arrived */
+int derp_seq_level_filter(derp_seq* seq, int level);       /* temporal filter of every owned frame + Transfer; fails
+                                                            * unless compute (and, with halo frames, the exchange) of
+                                                            * this level completed first */
 int derp_seq_run(derp_seq* seq, int level_start, int level_end);
 int derp_seq_stats(derp_seq* seq, uint64_t* bytes_sent, uint64_t* bytes_received, double* exchange_ms);
 int derp_seq_stats_reset(derp_seq* seq);

@@ -2,7 +2,8 @@
 """Freezes the oracle's output on the 'tiny' synthetic rig (4 cameras, 96x96, 3 levels) into
 tests/golden/oracle_tiny.npz: inputs are regenerated deterministically by the test; the file holds
 the expected level-0 / level-2 disparities with and without foreground masks, table samples, and the
-sibling stages (rephotography render + SSIM / NCC maps + mean score, foreground mask, layer compositing).
+sibling stages (rephotography render + SSIM / NCC maps + mean score, foreground mask, layer compositing), and the
+level-0 result of a 3-frame sequence run through the per-level temporal-filter schedule (BASELINE config 3).
 Run from the repo root:  python tests/golden/gen_oracle_goldens.py"""
 import os
 import sys
@@ -58,6 +59,14 @@ def run():
     out["fgmask_cam0"] = O.generate_foreground_mask(cols[0], frame1["color"][0][0], 1, 0.04, 4)
     out["layers_cam0"] = O.layer_disparities(np.where(frame["masks"][0][0] == 1, disps[0], 0).astype(np.float32),
                                              frame["bg_disp"][0][0])
+    # BASELINE config 3's schedule in miniature: 3 frames, per-level temporal filter seeding the next level
+    from facebook360_dep_amd import sequence
+
+    seq = common.OracleSequence(rig, sizes, res, 0, 2, threads=-1)
+    sequence.run_schedule(seq, list(range(len(sizes) - 1, -1, -1)), 0, 2, 0, 1)
+    out["seq3_l0"] = np.stack([seq.disp[t][0].numpy() for t in range(3)])
+    out["seq3_raw_l2_frame1"] = seq.raw[(1, len(sizes) - 1)]
+    out["seq3_input_color_l1_cam0_frame2"] = seq.frames[2]["color"][1][0]
     return out
 
 

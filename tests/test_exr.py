@@ -1,0 +1,66 @@
+"""--output_formats=exr (PyramidLevel.h:515-516 -> cv::imwrite of a CV_32FC1): the executables' OpenEXR writer
+(cli/cli_common.h, write_exr_f32) against the reader in facebook360_dep_amd/imageio.py, on the CPU: sizes that end in a
+short last block of scan lines, NaN, data that deflate cannot shrink (stored raw), and the header's fixed fields.
+Both ends follow the published OpenEXR file layout; no OpenEXR build exists in this image to pin them to (parity
+unpinned, like every OpenCV codec of SURVEY 8c)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SRC = r'''
+#include "%s/facebook360_dep_amd/cli/cli_common.h"
+int main(int argc, char** argv) {
+  const int w = atoi(argv[2]), h = atoi(argv[3]), noise = atoi(argv[4]);
+  std::vector<float> m((size_t)w * h);
+  uint32_t s = 12345;
+  for (size_t i = 0; i < m.size(); ++i) {
+    s = s * 1664525u + 1013904223u;
+    if (noise) {
+      memcpy(&m[i], &s, 4);  // arbitrary bit patterns (NaNs with payloads among them): deflate cannot shrink these
+    } else {
+      m[i] = (i %% 7 == 0) ? NAN : (float)(std::sin(i * 0.001) * 0.5 + (i %% 13) * 1e-3);
+    }
+  }
+  cli::write_exr_f32(argv[1], m.data(), w, h);
+  cli::write_pfm(std::string(argv[1]) + ".pfm", m.data(), w, h);
+  return 0;
+}
+'''
+
+
+@pytest.fixture(scope="module")
+def exr_tool(tmp_path_factory):
+    d = tmp_path_factory.mktemp("exr")
+    src = d / "t.cpp"
+    src.write_text(SRC % ROOT)
+    exe = str(d / "t")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe, "-lz",
+                           "-lpthread"])
+    return exe
+
+
+@pytest.mark.parametrize("w,h,noise", [(97, 35, 0), (64, 16, 0), (5, 1, 0), (33, 48, 1)])
+def test_exr_writer_against_reader(exr_tool, tmp_path, w, h, noise):
+    from facebook360_dep_amd import imageio as dio
+
+    path = str(tmp_path / "a.exr")
+    subprocess.check_call([exr_tool, path, str(w), str(h), str(noise)])
+    got, want = dio.read_exr(path), dio.read_pfm(path + ".pfm")
+    assert got.shape == (h, w) and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x76\x2f\x31\x01\x02\x00\x00\x00"  # magic, version 2, single-part scan-line
+    assert b"channels\0chlist\0" in data and b"compression\0compression\0\x01\0\0\0\x03" in data  # ZIP, 16-line blocks
+    i = data.index(b"dataWindow\0box2i\0") + len(b"dataWindow\0box2i\0") + 4
+    assert struct.unpack_from("<4i", data, i) == (0, 0, w - 1, h - 1)
+    if noise:  # stored raw: chunk size = lines * w * 4
+        blocks = (h + 15) // 16
+        hdr_end = data.index(b"screenWindowWidth\0float\0") + len(b"screenWindowWidth\0float\0") + 4 + 4 + 1
+        off0, = struct.unpack_from("<Q", data, hdr_end)
+        assert off0 == hdr_end + 8 * blocks
+        y, size = struct.unpack_from("<ii", data, off0)
+        assert y == 0 and size == 16 * w * 4

@@ -202,6 +202,24 @@ def test_derp_sequence_cli_equals_the_three_binary_pipeline(dataset, tmp_path):
     name = os.path.join("disparity_levels", "level_0", ids[1], "000001.pfm")
     assert open(os.path.join(out_c, name), "rb").read() == open(os.path.join(out_d, name), "rb").read()
     assert not os.path.exists(os.path.join(out_c, "disparity_time_filtered_levels", "level_0", ids[1], "000001.pfm"))
+    # out of core (--resident_frames): one frame slot in HBM, the frames stream level by level from host memory —
+    # same files, byte for byte, with the filter (window of one frame: time_radius 0) and without it
+    out_e, out_f, out_g = str(tmp_path / "e"), str(tmp_path / "f"), str(tmp_path / "g")
+    p = run("DerpSequence", *common_flags, "--output_root=" + out_e, "--time_radius=0", "--resident_frames=1")
+    assert "1 frame slot(s) in HBM (out of core)" in p.stderr
+    run("DerpSequence", *common_flags, "--output_root=" + out_f, "--time_radius=0")
+    run("DerpSequence", *common_flags, "--output_root=" + out_g, "--do_temporal_filter=false", "--resident_frames=1")
+    for level in range(n_levels):
+        for cam in ids:
+            for f in range(3):
+                name = os.path.join("disparity_levels", "level_%d" % level, cam, "%06d.pfm" % f)
+                assert open(os.path.join(out_e, name), "rb").read() == open(os.path.join(out_f, name), "rb").read(), name
+                assert open(os.path.join(out_g, name), "rb").read() == open(os.path.join(out_c, name), "rb").read(), name
+    # PNG only at the finest level (pipeline.py:366-369 forces PFM above it)
+    out_h = str(tmp_path / "h")
+    run("DerpSequence", *common_flags, "--output_root=" + out_h, "--output_formats=pfm,png")
+    assert os.path.exists(os.path.join(out_h, "disparity_levels", "level_0", ids[0], "000000.png"))
+    assert not os.path.exists(os.path.join(out_h, "disparity_levels", "level_1", ids[0], "000000.png"))
 
 
 def test_derp_sequence_cli_masks_subset_and_resume(dataset, tmp_path):
@@ -278,11 +296,24 @@ def test_derp_sequence_failing_rank_takes_the_job_down(dataset, tmp_path):
     assert time.time() - t0 < 120
 
 
-def test_output_format_exr_alone_is_refused(dataset, tmp_path):
-    """PyramidLevel.h:515-516 writes .exr through OpenCV; this build has no EXR encoder and says so."""
-    p = run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "o"), "--partial_coverage",
-            "--resolution=96", "--output_formats=exr", expect_ok=False)
-    assert p.returncode != 0 and "exr is not supported" in p.stderr
+def test_output_format_exr(dataset, tmp_path):
+    """--output_formats=exr (PyramidLevel.h:515-516): a scan-line OpenEXR with one FLOAT channel next to the PFM that
+    is always written — same floats, bit for bit (NaN outside the FOV included); an unknown format is refused."""
+    from facebook360_dep_amd import imageio as dio
+
+    out = str(tmp_path / "o")
+    run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + out, "--first=000000", "--last=000000",
+        "--partial_coverage", "--resolution=96", "--output_formats=exr")
+    ids = [c["id"] for c in dataset["rig"]["cameras"]]
+    for level in range(len(dataset["sizes"])):
+        base = os.path.join(out, "disparity_levels", "level_%d" % level, ids[1], "000000")
+        a, b = dio.read_pfm(base + ".pfm"), dio.read_exr(base + ".exr")
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert open(base + ".exr", "rb").read(8) == b"\x76\x2f\x31\x01\x02\x00\x00\x00"
+        assert not os.path.exists(base + ".png")
+    p = run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "x"), "--first=000000",
+            "--last=000000", "--partial_coverage", "--resolution=96", "--output_formats=tiff", expect_ok=False)
+    assert p.returncode != 0 and "Invalid output format" in p.stderr
 
 
 def test_upsample_cli(dataset, tmp_path):

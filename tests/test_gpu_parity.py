@@ -133,6 +133,26 @@ def test_against_committed_golden_fixture(built):
     for d in range(n):
         assert common.compare_disparity(g.download_disparity(0, d), gold["fg_l0"][d], TOL)[0] == 0
     g.close()
+    # BASELINE config 3's schedule (3 frames, temporal filter at every level) against the committed result
+    from facebook360_dep_amd import sequence
+
+    g = derp.Derp(rig["cameras"], partial_coverage=1)
+    g.set_pyramid(sizes, res, res)
+    r = sequence.SequenceRunner(g, 0, 2)
+    for t in r.owned:
+        fr = synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu")
+        if t == 2:  # the rendering does not depend on the host that renders it
+            assert np.array_equal(fr["color"][1][0], gold["seq3_input_color_l1_cam0_frame2"])
+        r.upload_frame(t, fr)
+    r.compute(len(sizes) - 1)
+    g.synchronize()
+    assert _float_equal(np.stack([r.download_disparity(1, len(sizes) - 1, d) for d in range(n)]), gold["seq3_raw_l2_frame1"]) == 0
+    r.run()
+    g.synchronize()
+    for t in range(3):
+        for d in range(n):
+            assert _float_equal(r.download_disparity(t, 0, d), gold["seq3_l0"][t][d]) == 0, (t, d)
+    g.close()
 
 
 def test_cost_map(small, gpu):

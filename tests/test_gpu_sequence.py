@@ -298,6 +298,114 @@ def test_sequence_foreground_masks(built):
         g.close()
 
 
+def _levels_equal(a, b, frames, n, sizes):
+    for t in frames:
+        for level in range(len(sizes)):
+            for d in range(n):
+                assert _bad(a.download_disparity(t, level, d), b.download_disparity(t, level, d)) == 0, (t, level, d)
+
+
+@pytest.mark.parametrize("masks", [False, True])
+def test_sequence_out_of_core_equals_resident(built, masks):
+    """resident_frames = 2R + 1 = 5 device slots for 8 owned frames: inputs stream per level from host memory, raw
+    levels and results live in page-locked host buffers — every level of every frame equals the fully resident run
+    bit for bit (with and without foreground masks / temporal masking), and both equal the oracle."""
+    from facebook360_dep_amd import derp, sequence, synth
+
+    n, res, rig, sizes = _setup("tiny")
+    first, last = 0, 7
+
+    def run(resident):
+        g = derp.Derp(rig["cameras"], partial_coverage=1, use_foreground_masks=int(masks))
+        g.set_pyramid(sizes, res, res)
+        r = sequence.SequenceRunner(g, first, last, 0, 1, use_foreground_masks=int(masks), resident_frames=resident)
+        for t in r.owned:
+            r.upload_frame(t, synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu", with_masks=masks))
+        r.run()
+        g.synchronize()
+        return g, r
+
+    g0, r0 = run(0)
+    g1, r1 = run(5)
+    assert not r0.streaming and r1.streaming and g1.frame_slots()[0] == 5 and g0.frame_slots()[0] == 8
+    _levels_equal(r0, r1, range(first, last + 1), n, sizes)
+    if not masks:
+        ref = _oracle_sequence("tiny", first, last)
+        assert _compare_with_oracle([r1], ref, n, sizes) == 0
+    g0.close()
+    g1.close()
+    with pytest.raises(derp.DerpError):  # fewer slots than the temporal window
+        g = derp.Derp(rig["cameras"], partial_coverage=1)
+        g.set_pyramid(sizes, res, res)
+        try:
+            sequence.SequenceRunner(g, first, last, 0, 1, resident_frames=3)
+        finally:
+            g.close()
+
+
+def test_sequence_out_of_core_two_ranks_and_no_filter(built):
+    """Out of core on two emulated ranks (6 owned frames each, 5 slots: the frames the neighbour's window reaches
+    into keep fixed device buffers for the exchange) equals the resident single-rank run; without the temporal
+    filter ONE slot serves any number of frames."""
+    from facebook360_dep_amd import derp, sequence, synth
+
+    n, res, rig, sizes = _setup("tiny")
+    first, last = 0, 11
+    g0, r0 = _gpu_runner(rig, sizes, res, first, last)
+    r0.run()
+    made = [_gpu_runner(rig, sizes, res, first, last, rank, 2, resident_frames=5) for rank in range(2)]
+    runners = [r for (_, r) in made]
+    assert all(r.streaming for r in runners)
+    sequence.run_loopback(runners, len(sizes) - 1)
+    for r in runners:
+        _levels_equal(r0, r, r.owned, n, sizes)
+    plan = sequence.plan(first, last, 2, 2, 0)
+    px = sum(w * h for (w, h) in sizes)
+    assert sum(r.stats()["bytes_received"] for r in runners) == len(plan) * px * n * (8 + 4)
+    for (g, r) in made:
+        g.close()
+    g0.close()
+    g2, r2 = _gpu_runner(rig, sizes, res, 0, 3, do_temporal_filter=0, resident_frames=1)
+    g3, r3 = _gpu_runner(rig, sizes, res, 0, 3, do_temporal_filter=0)
+    r2.run()
+    r3.run()
+    assert r2.streaming and g2.frame_slots()[0] == 1
+    _levels_equal(r2, r3, range(4), n, sizes)
+    g2.close()
+    g3.close()
+
+
+def test_sequence_phases_out_of_order_are_refused(built):
+    """derp_seq_level_filter without the level's compute, or (with halo frames) without its exchange, fails
+    instead of filtering stale data."""
+    from facebook360_dep_amd import derp, sequence
+
+    n, res, rig, sizes = _setup("tiny")
+    top = len(sizes) - 1
+    g, r = _gpu_runner(rig, sizes, res, 0, 2)
+    with pytest.raises(derp.DerpError):
+        r.filter(top)
+    r.compute(top)
+    r.filter(top)  # one rank: nothing to exchange
+    g.close()
+    made = [_gpu_runner(rig, sizes, res, 0, 3, rank, 2) for rank in range(2)]
+    runners = [r for (_, r) in made]
+    for r in runners:
+        r.attach_loopback(runners)
+    for r in runners:
+        r.exchange_inputs()
+    for r in runners:
+        r.compute(top)
+    with pytest.raises(derp.DerpError):
+        runners[0].filter(top)  # halo level not exchanged yet
+    for r in runners:
+        r.exchange_level(top)
+    for r in runners:
+        r.filter(top)
+    for (g, r) in made:
+        g.close()
+
+
 def test_sequence_without_temporal_filter_is_replicas(built):
     """do_temporal_filter = 0: no halo, no exchange, every frame equals a stand-alone pyramid."""
     from facebook360_dep_amd import derp, synth

@@ -26,17 +26,18 @@ root = tempfile.mkdtemp(prefix="derp_cli_", dir="/tmp")
 t0 = time.time()
 synth.write_dataset(root, rig, list(range(frames)), sizes)
 print("dataset: %d frame(s) of %s written in %.1f s under %s" % (frames, cfg, time.time() - t0, root))
-for binary in binary.split(","):
-    out = os.path.join(root, "out_" + binary)
+for binary, threads in [(b, t) for b in binary.split(",") for t in threads.split(",")]:
+    out = os.path.join(root, "out_%s_%s" % (binary, threads))
     t0 = time.time()
     p = subprocess.run([os.path.join(ROOT, "facebook360_dep_amd", "bin", binary), "--input_root=" + root,
                         "--output_root=" + out, "--first=000000", "--last=%06d" % (frames - 1), "--resolution=%d" % res,
                         "--threads=" + threads] + (["--partial_coverage"] if n <= 4 else []), capture_output=True, text=True)
     wall = time.time() - t0
-    print("%s rc=%d, wall %.2f s for %d frame(s) = %.1f Mpix/s from disk to disk" % (
-        binary, p.returncode, wall, frames, frames * n * res * res / wall / 1e6))
+    print("%s --threads=%s rc=%d, wall %.2f s for %d frame(s) = %.1f Mpix/s from disk to disk" % (
+        binary, threads, p.returncode, wall, frames, frames * n * res * res / wall / 1e6))
     for line in p.stderr.splitlines():
-        if "-- I/O" in line or "-- TOTAL" in line or "-- rank" in line or "-- inputs" in line or re.search(r"level 0\)$", line):
+        if "-- I/O" in line or "-- TOTAL" in line or "-- rank" in line or "-- inputs" in line or "-- start-up" in line or \
+                re.search(r"\(level \d+\)$", line):
             print(line)
     if p.returncode:
         print(p.stderr[-2000:])
