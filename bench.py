@@ -56,6 +56,17 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_sources_sha256():
+    """Same definition as tools/make_profiles.py: the sources the device code is built from."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("derp_kernels.h", "derp_capi.hip", "derp_camera.h", "gcc_algos.h", "derp_sequence.h"):
+        with open(os.path.join(ROOT, "facebook360_dep_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def b_alg(n_cost, n_pair):
     """logical gather bytes of the cost loop."""
     return 64.0 * n_cost + 272.0 * n_pair
@@ -228,7 +239,7 @@ def main():
                 "bytes_received_per_step": sum(e["bytes_received_per_step"] for e in gathered)}
 
     # ---- roofline of the dominant kernel: level-0 ping-pong (one launch per frame per step)
-    prof = {}
+    prof, stale = {}, None
     ppath = os.path.join(ROOT, "profiles", "valu_roofline.json")
     if os.path.exists(ppath):
         try:
@@ -236,6 +247,13 @@ def main():
                 prof = json.load(f).get(args.config, {})
         except Exception:  # noqa: BLE001
             prof = {}
+    # the counter numerators were collected on ONE version of the kernels: with any other, cycles and time would
+    # come from different programs, so the counter-derived fields are withheld (tools/profile_round.sh re-collects)
+    here = kernel_sources_sha256()
+    if prof and prof.get("kernel_sources_sha256") != here:
+        stale = ("profiles/valu_roofline.json was collected on kernel sources %s..., this tree is %s...: counter-derived "
+                 "fields withheld" % (str(prof.get("kernel_sources_sha256"))[:12], here[:12]))
+        prof = {}
     n_cost_launch = pp["n_cost"] / launches
     n_pair_launch = pp["n_pair"] / launches
     # executed = logical minus the evaluations served from the memo (their pairs are not executed either)
@@ -259,16 +277,23 @@ def main():
                  "profiles/valu_roofline.json; quad-cycles x 4) / this run's HIP-event launch duration; peak = "
                  "%d SIMDs x %.1f GHz. The kernel gathers from L1/L2-resident tables: HBM is not its bound "
                  "(hbm_frac below), VALU issue is." % (N_SIMD, PEAK_CLOCK_GHZ)),
+        "stale": stale,
         "valu_busy_frac_at_measured_clock": prof.get("ping_pong_level0_valu_busy_frac"),
+        # second numerator (VALU wave-instructions x 4 cycles); see profiles/README.md for how the two relate
+        "frac_by_instruction_count": (round(prof["ping_pong_level0_valu_insts_x4_cycles_per_launch"] / kernel_s / 1e9
+                                            / VALU_PEAK_GCYC, 4)
+                                      if prof.get("ping_pong_level0_valu_insts_x4_cycles_per_launch") and kernel_s > 0 else None),
+        "waves_per_simd": prof.get("ping_pong_level0_waves_per_simd"),
         "wave_issue_breakdown": prof.get("ping_pong_level0_wave_cycle_shares"),
         "hbm_traffic_GBps": round(traffic / kernel_s / 1e9, 1) if traffic and kernel_s > 0 else None,
         "hbm_frac": round(traffic / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_s > 0 else None,
         "algorithmic": {  # SURVEY 8(d)'s logical gather bytes: secondary, on EXECUTED evaluations only
             "bytes_per_launch_executed": alg_bytes_exec,
             "GBps": round(alg_bytes_exec / kernel_s / 1e9, 1) if kernel_s > 0 else None,
-            "frac_of_hbm_peak": round(alg_bytes_exec / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if kernel_s > 0 else None,
-            "note": "logical gathers (64 B / cost call + 272 B / (call, source) pair); neighbouring pixels share "
-                    "texels and L1/L2 serve them, so this can exceed the HBM peak and is not a bound",
+            "logical_rate_over_hbm_peak_NOT_A_BOUND": round(alg_bytes_exec / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if kernel_s > 0 else None,
+            "note": "SURVEY 8(d)'s B_alg: logical gathers (64 B / cost call + 272 B / (call, source) pair); neighbouring "
+                    "pixels share texels and L1/L2 serve them, so this ratio exceeds 1 and bounds nothing. The HBM "
+                    "fraction 8(d) asks for is hbm_frac above: measured traffic of the launch / 8 TB/s",
             "n_cost_per_launch": n_cost_launch, "n_pair_per_launch": n_pair_launch,
             "memoised_cost_evals_per_launch": memo,
         },

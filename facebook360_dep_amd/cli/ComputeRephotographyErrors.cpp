@@ -8,7 +8,7 @@
 // DESIGN.md §8), and compared with the reference's score arithmetic (derp_ssim / derp_average_score) under the
 // reference cubemap's alpha mask. The second cubemap pair of the reference (disparity colours) only feeds its
 // plot and is not rendered.
-#include "cli_common.h"
+#include "derp_job.h"
 
 using namespace cli;
 
@@ -71,6 +71,7 @@ int main(int argc, char** argv) {
   if (derp_create(&ctx, F.i("device"), rig.data(), (int)rig.size(), rig.data(), (int)rig.size()) != 0) {
     LOG_FATAL(std::string("derp_create failed: ") + derp_last_error(nullptr));
   }
+  IoPool pool(-1);
   const fs::path rephotoDir = fs::path(F.s("output")) / "rephoto";
   for (const auto& cam : rig) {
     fs::create_directories(rephotoDir / cam.id);
@@ -86,22 +87,26 @@ int main(int argc, char** argv) {
     int w = 0, h = 0;
     std::vector<std::vector<float>> disps(rig.size());
     std::vector<std::vector<uint16_t>> colors(rig.size());
+    std::vector<int> dws(rig.size()), dhs(rig.size()), cws(rig.size()), chs(rig.size());
+    {  // one decode job per file on the I/O pool
+      IoBatch loads;
+      for (size_t i = 0; i < rig.size(); ++i) {
+        loads.add(pool, [&, i] {
+          disps[i] = read_pfm(fs::path(F.s("disparity")) / rig[i].id / (frame + ".pfm"), dws[i], dhs[i]);
+        });
+        loads.add(pool, [&, i] { colors[i] = load_color_bgr16(image_path(F.s("color"), rig[i].id, frame), cws[i], chs[i]); });
+      }
+      loads.wait();
+    }
+    w = dws[0];
+    h = dhs[0];
     for (size_t i = 0; i < rig.size(); ++i) {
-      int dw, dh;
-      disps[i] = read_pfm(fs::path(F.s("disparity")) / rig[i].id / (frame + ".pfm"), dw, dh);
-      if (i == 0) {
-        w = dw;
-        h = dh;
-      }
-      CHECK_MSG(dw == w && dh == h, "disparity sizes differ between cameras");
-      int cw, ch;
-      std::vector<uint16_t> img = load_color_bgr16(image_path(F.s("color"), rig[i].id, frame), cw, ch);
-      if (cw != w || ch != h) {  // loadResizedImages(..., disps[0].size(), INTER_AREA)
+      CHECK_MSG(dws[i] == w && dhs[i] == h, "disparity sizes differ between cameras");
+      if (cws[i] != w || chs[i] != h) {  // loadResizedImages(..., disps[0].size(), INTER_AREA)
         std::vector<uint16_t> out((size_t)w * h * 3);
-        DERP_OK(ctx, derp_resize_area(ctx, 0, img.data(), cw, ch, out.data(), w, h));
-        img.swap(out);
+        DERP_OK(ctx, derp_resize_area(ctx, 0, colors[i].data(), cws[i], chs[i], out.data(), w, h));
+        colors[i].swap(out);
       }
-      colors[i].swap(img);
     }
     std::vector<const uint16_t*> cp(rig.size());
     std::vector<const float*> dp(rig.size());
@@ -114,6 +119,17 @@ int main(int argc, char** argv) {
     int used = 0;
     const int E = h;  // cubeHeight = colors[0].rows (ComputeRephotographyErrors.cpp:126)
     const size_t nc = (size_t)6 * E * E;
+    // the cubemaps are hundreds of MB at full size: page-locked buffers (transfers at the PCIe rate), allocated once
+    Arena aRef, aRender, aX, aY, aScore;
+    aRef.ensure(nc * 4 * sizeof(float));
+    aRender.ensure(nc * 4 * sizeof(float));
+    aX.ensure(nc * 3 * sizeof(float));
+    aY.ensure(nc * 3 * sizeof(float));
+    aScore.ensure(nc * 3 * sizeof(float));
+    float *cubeRef = static_cast<float*>(aRef.p), *cubeRender = static_cast<float*>(aRender.p);
+    float *x = static_cast<float*>(aX.p), *y = static_cast<float*>(aY.p), *score = static_cast<float*>(aScore.p);
+    std::vector<uint8_t> mask(nc);
+    IoBatch plots;  // the PNG plots are encoded and written behind the next camera's rendering
     for (size_t i = 0; i < rig.size(); ++i) {
       const std::string camId = rig[i].id;
       if (!only.empty() && std::find(only.begin(), only.end(), camId) == only.end()) {
@@ -125,23 +141,21 @@ int main(int argc, char** argv) {
       std::vector<uint8_t> onlyI(rig.size(), 0), allButI(rig.size(), 1);
       onlyI[i] = 1;
       allButI[i] = 0;
-      std::vector<float> cubeRef(nc * 4), cubeRender(nc * 4);
-      DERP_OK(ctx, derp_canopy_cubemap(ctx, onlyI.data(), rig[i].origin, E, cubeRef.data()));
-      DERP_OK(ctx, derp_canopy_cubemap(ctx, allButI.data(), rig[i].origin, E, cubeRender.data()));
+      DERP_OK(ctx, derp_canopy_cubemap(ctx, onlyI.data(), rig[i].origin, E, cubeRef));
+      DERP_OK(ctx, derp_canopy_cubemap(ctx, allButI.data(), rig[i].origin, E, cubeRender));
       // mask = 255 * (alpha > 0) of the reference cubemap; removeAlpha on both (:147-155)
-      std::vector<float> x(nc * 3), y(nc * 3);
-      std::vector<uint8_t> mask(nc);
-      for (size_t k = 0; k < nc; ++k) {
-        mask[k] = cubeRef[4 * k + 3] > 0;
-        for (int c = 0; c < 3; ++c) {
-          x[3 * k + c] = cubeRef[4 * k + c];
-          y[3 * k + c] = cubeRender[4 * k + c];
+      parallel_rows(pool, 6 * E, [&](int r0, int r1) {
+        for (size_t k = (size_t)r0 * E; k < (size_t)r1 * E; ++k) {
+          mask[k] = cubeRef[4 * k + 3] > 0;
+          for (int c = 0; c < 3; ++c) {
+            x[3 * k + c] = cubeRef[4 * k + c];
+            y[3 * k + c] = cubeRender[4 * k + c];
+          }
         }
-      }
-      std::vector<float> score(nc * 3);
-      DERP_OK(ctx, derp_ssim(ctx, x.data(), y.data(), E, 6 * E, F.i("stat_radius"), abg, abg, 1.0f, score.data()));
+      });
+      DERP_OK(ctx, derp_ssim(ctx, x, y, E, 6 * E, F.i("stat_radius"), abg, abg, 1.0f, score));
       double avg[3];
-      CHECK_MSG(derp_average_score(score.data(), mask.data(), E, 6 * E, avg) == 0, "derp_average_score");
+      CHECK_MSG(derp_average_score(score, mask.data(), E, 6 * E, avg) == 0, "derp_average_score");
       LOG_INFO(camId + " " + method + ": " + format_results(avg));
       for (int c = 0; c < 3; ++c) {
         frameScore[c] += avg[c];
@@ -150,21 +164,29 @@ int main(int argc, char** argv) {
       // plot: reference | rendered | score cubemaps side by side, 8 bit (stackResults without the colour map
       // and the caption)
       const int pw = 3 * E, ph = 6 * E;
-      std::vector<uint16_t> plot((size_t)pw * ph * 3);
+      auto plot = std::make_shared<std::vector<uint16_t>>((size_t)pw * ph * 3);
       auto to8 = [](float v) { return (uint16_t)(v <= 0 ? 0 : v >= 1 ? 255 : lrintf(v * 255.0f)); };
-      for (int yy = 0; yy < ph; ++yy) {
-        for (int xx = 0; xx < E; ++xx) {
-          const size_t k = (size_t)yy * E + xx;
-          for (int c = 0; c < 3; ++c) {
-            const int rgb = 2 - c;  // write_png takes RGB
-            plot[((size_t)yy * pw + xx) * 3 + rgb] = to8(x[3 * k + c]);
-            plot[((size_t)yy * pw + E + xx) * 3 + rgb] = mask[k] ? to8(y[3 * k + c]) : 0;
-            const float sc = score[3 * k + c];
-            plot[((size_t)yy * pw + 2 * E + xx) * 3 + rgb] = mask[k] && sc == sc ? to8(sc) : 0;
+      parallel_rows(pool, ph, [&](int r0, int r1) {
+        uint16_t* out = plot->data();
+        for (int yy = r0; yy < r1; ++yy) {
+          for (int xx = 0; xx < E; ++xx) {
+            const size_t k = (size_t)yy * E + xx;
+            for (int c = 0; c < 3; ++c) {
+              const int rgb = 2 - c;  // write_png takes RGB
+              out[((size_t)yy * pw + xx) * 3 + rgb] = to8(x[3 * k + c]);
+              out[((size_t)yy * pw + E + xx) * 3 + rgb] = mask[k] ? to8(y[3 * k + c]) : 0;
+              const float sc = score[3 * k + c];
+              out[((size_t)yy * pw + 2 * E + xx) * 3 + rgb] = mask[k] && sc == sc ? to8(sc) : 0;
+            }
           }
         }
-      }
-      write_png(rephotoDir / camId / (frame + ".png"), plot.data(), pw, ph, 3, 8);
+      });
+      const fs::path plotPath = rephotoDir / camId / (frame + ".png");
+      plots.add(pool, [plot, plotPath, pw, ph] { write_png(plotPath, plot->data(), pw, ph, 3, 8); });
+    }
+    plots.wait();
+    for (Arena* a : {&aRef, &aRender, &aX, &aY, &aScore}) {
+      a->release();
     }
     const int nCams = !only.empty() ? (int)only.size() : (int)rig.size();
     (void)used;

@@ -1081,6 +1081,21 @@ struct IoBatch {
   }
 };
 
+// rows [0, n) split into contiguous chunks over the pool; returns when all of them ran
+inline void parallel_rows(IoPool& pool, int n, const std::function<void(int, int)>& body) {
+  const int parts = std::max(1, std::min(n, (int)pool.workers.size()));
+  if (parts <= 1) {
+    body(0, n);
+    return;
+  }
+  IoBatch batch;
+  for (int p = 0; p < parts; ++p) {
+    const int a = (int)((long long)n * p / parts), b = (int)((long long)n * (p + 1) / parts);
+    batch.add(pool, [=, &body] { body(a, b); });
+  }
+  batch.wait();
+}
+
 struct Timer {
   timespec t0;
   Timer() { clock_gettime(CLOCK_MONOTONIC, &t0); }

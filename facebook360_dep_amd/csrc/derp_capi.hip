@@ -97,6 +97,7 @@ struct derp_ctx {
   hipStream_t stream = nullptr;
   hipStream_t copyStream = nullptr;  // input uploads of a frame that is not being computed (sequence driver), with
   DevBuf copyStaging;                // their own staging buffer: they overlap the compute of the frame before
+  DevBuf cnVert, cnRgba, cnZ, cnAcc, cnOut, cnBig, cnNBig;  // derp_canopy_cubemap's buffers, kept between calls
   std::string err;
   derp_options opt;
   int S = 0, D = 0;
@@ -1075,7 +1076,12 @@ void derp_destroy(derp_ctx* c) {
   c->fullFrame.release();
   c->rephotoColor.release();
   c->rephotoDisp.release();
+  c->copyStaging.release();
+  for (DevBuf* b : {&c->cnVert, &c->cnRgba, &c->cnZ, &c->cnAcc, &c->cnOut, &c->cnBig, &c->cnNBig}) {
+    b->release();
+  }
   (void)hipStreamDestroy(c->stream);
+  (void)hipStreamDestroy(c->copyStream);
   delete c;
 }
 
@@ -1816,28 +1822,71 @@ int derp_canopy_cubemap(derp_ctx* c, const uint8_t* include, const double* centr
   HIPCHK(c, hipSetDevice(c->device));
   const int w = c->rephotoW, h = c->rephotoH, E = edge;
   const size_t n = (size_t)w * h, nf = (size_t)E * E;
-  DevBuf vert, rgba, zbuf, acc, out;
+  // mip chain geometry (glGenerateMipmap): level sizes halve, rounding down, never below 1
+  CanopyMips M;
+  M.n = 0;
+  size_t texels = 0;
+  for (int lw = w, lh = h;; lw = std::max(1, lw >> 1), lh = std::max(1, lh >> 1)) {
+    if (M.n >= kCanopyMaxLevels) {
+      return fail(c, "image too large for the mip chain");
+    }
+    M.w[M.n] = lw;
+    M.h[M.n] = lh;
+    M.off[M.n] = (unsigned)texels;
+    texels += (size_t)lw * lh;
+    ++M.n;
+    if (lw == 1 && lh == 1) {
+      break;
+    }
+  }
+  int nInc = 0;
+  for (int s = 0; s < c->S; ++s) {
+    nInc += include[s] != 0;
+  }
+  // per included camera: mesh vertices + the colour mip chain, built once and reused by the six faces
+  DevBuf &vert = c->cnVert, &rgba = c->cnRgba, &zbuf = c->cnZ, &acc = c->cnAcc, &out = c->cnOut, &big = c->cnBig,
+         &nBig = c->cnNBig;
   int rc = 0;
-  if (vert.ensure(n * 16) || rgba.ensure(n * 16) || zbuf.ensure(nf * 8) || acc.ensure(nf * 16) || out.ensure(nf * 6 * 16)) {
+  if (vert.ensure((size_t)std::max(nInc, 1) * n * 16) || rgba.ensure((size_t)std::max(nInc, 1) * texels * 16) ||
+      zbuf.ensure(nf * 8) || acc.ensure(nf * 16) || out.ensure(nf * 6 * 16) || big.ensure(n * 2 * sizeof(unsigned)) ||
+      nBig.ensure(sizeof(unsigned))) {
     rc = fail(c, "out of device memory");
   } else {
     const float cx = (float)centre[0], cy = (float)centre[1], cz = (float)centre[2];  // position.cast<float>()
-    // meshes are needed once per camera, faces reuse them: camera-outer would redo the accumulation order, so keep
-    // the reference's order (face-outer, camera-inner) and rebuild the small mesh per (face, camera)
+    std::vector<int> slotOf(c->S, -1);
+    for (int s = 0, k = 0; s < c->S; ++s) {
+      if (!include[s]) {
+        continue;
+      }
+      slotOf[s] = k;
+      float4* v = vert.as<float4>() + (size_t)k * n;
+      float4* tex = rgba.as<float4>() + (size_t)k * texels;
+      hipLaunchKernelGGL(k_canopy_mesh, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), s,
+                         c->rephotoColor.as<uint16_t>() + (size_t)s * n * 3, c->rephotoDisp.as<float>() + (size_t)s * n, w,
+                         h, v, tex);
+      for (int l = 1; l < M.n; ++l) {
+        hipLaunchKernelGGL(k_canopy_mip, grid2d(M.w[l], M.h[l], 1, kBlk2d), kBlk2d, 0, c->stream, tex + M.off[l - 1],
+                           M.w[l - 1], M.h[l - 1], tex + M.off[l], M.w[l], M.h[l]);
+      }
+      ++k;
+    }
+    // the reference's order: face-outer, camera-inner (the accumulation order of the cameras is part of the result)
     for (int face = 0; face < 6 && !rc; ++face) {
       (void)hipMemsetAsync(acc.p, 0, nf * 16, c->stream);
       for (int s = 0; s < c->S; ++s) {
         if (!include[s]) {
           continue;
         }
-        hipLaunchKernelGGL(k_canopy_mesh, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, c->camsSrc.as<Cam>(), s,
-                           c->rephotoColor.as<uint16_t>() + (size_t)s * n * 3, c->rephotoDisp.as<float>() + (size_t)s * n, w,
-                           h, vert.as<float4>(), rgba.as<float4>());
+        const float4* v = vert.as<float4>() + (size_t)slotOf[s] * n;
+        const float4* tex = rgba.as<float4>() + (size_t)slotOf[s] * texels;
         (void)hipMemsetAsync(zbuf.p, 0, nf * 8, c->stream);
-        hipLaunchKernelGGL(k_canopy_raster, grid2d(w - 1, h - 1, 2, kBlk2d), kBlk2d, 0, c->stream, vert.as<float4>(),
-                           rgba.as<float4>(), w, h, cx, cy, cz, face, E, zbuf.as<unsigned long long>());
-        hipLaunchKernelGGL(k_canopy_resolve, grid2d(E, E, 1, kBlk2d), kBlk2d, 0, c->stream, vert.as<float4>(),
-                           rgba.as<float4>(), w, h, cx, cy, cz, face, E, zbuf.as<unsigned long long>(), acc.as<float4>());
+        (void)hipMemsetAsync(nBig.p, 0, sizeof(unsigned), c->stream);
+        hipLaunchKernelGGL(k_canopy_raster, grid2d(w - 1, h - 1, 2, kBlk2d), kBlk2d, 0, c->stream, v, tex, M, w, h, cx, cy, cz,
+                           face, E, zbuf.as<unsigned long long>(), big.as<unsigned>(), nBig.as<unsigned>());
+        hipLaunchKernelGGL(k_canopy_raster_big, dim3(4096), dim3(256), 0, c->stream, v, tex, M, w, h, cx, cy, cz, face, E,
+                           zbuf.as<unsigned long long>(), big.as<unsigned>(), nBig.as<unsigned>());
+        hipLaunchKernelGGL(k_canopy_resolve, grid2d(E, E, 1, kBlk2d), kBlk2d, 0, c->stream, v, tex, M, w, h, cx, cy, cz, face, E,
+                           zbuf.as<unsigned long long>(), acc.as<float4>());
       }
       hipLaunchKernelGGL(k_canopy_finish, grid2d(E, E, 1, kBlk2d), kBlk2d, 0, c->stream, acc.as<float4>(), face, E,
                          out.as<float4>());
@@ -1849,9 +1898,6 @@ int derp_canopy_cubemap(derp_ctx* c, const uint8_t* include, const double* centr
                 hipMemcpy(out_bgra, out.p, nf * 6 * 16, hipMemcpyDeviceToHost) != hipSuccess)) {
       rc = fail(c, "HIP error in derp_canopy_cubemap: %s", hipGetErrorString(hipGetLastError()));
     }
-  }
-  for (DevBuf* b : {&vert, &rgba, &zbuf, &acc, &out}) {
-    b->release();
   }
   return rc;
 }

@@ -2197,15 +2197,39 @@ __device__ __forceinline__ void canopy_tex(const CanopyTri& T, float px, float p
   u = (l[0] * (T.tu[0] * T.invd[0]) + l[1] * (T.tu[1] * T.invd[1]) + l[2] * (T.tu[2] * T.invd[2])) / iz;
   v = (l[0] * (T.tv[0] * T.invd[0]) + l[1] * (T.tv[1] * T.invd[1]) + l[2] * (T.tv[2] * T.invd[2])) / iz;
 }
-__device__ __forceinline__ float4 canopy_sample(const float4* __restrict__ rgba, int W, int H, float u, float v) {
+// mip chain of one camera's RGBA texture (glGenerateMipmap): level k at texel offset off[k], size w[k] x h[k]
+constexpr int kCanopyMaxLevels = 16;
+constexpr int kCanopyMaxAniso = 16;  // GL_MAX_TEXTURE_MAX_ANISOTROPY of current hardware
+struct CanopyMips {
+  int n;
+  int w[kCanopyMaxLevels], h[kCanopyMaxLevels];
+  unsigned off[kCanopyMaxLevels];
+};
+// level k = 2x2 box of level k - 1 (an odd last row / column repeats its edge texel)
+__global__ void k_canopy_mip(const float4* __restrict__ src, int sw, int sh, float4* __restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= dw || y >= dh) {
+    return;
+  }
+  const int x0 = min(2 * x, sw - 1), x1 = min(2 * x + 1, sw - 1), y0 = min(2 * y, sh - 1), y1 = min(2 * y + 1, sh - 1);
+  const float4 a = src[(size_t)y0 * sw + x0], b = src[(size_t)y0 * sw + x1];
+  const float4 e = src[(size_t)y1 * sw + x0], f = src[(size_t)y1 * sw + x1];
+  dst[(size_t)y * dw + x] = make_float4(((a.x + b.x) + (e.x + f.x)) * 0.25f, ((a.y + b.y) + (e.y + f.y)) * 0.25f,
+                                        ((a.z + b.z) + (e.z + f.z)) * 0.25f, ((a.w + b.w) + (e.w + f.w)) * 0.25f);
+}
+// GL_LINEAR inside mip level k, clamp to edge
+__device__ __forceinline__ float4 canopy_bilinear(const float4* __restrict__ rgba, const CanopyMips& M, int k, float u,
+                                                  float v) {
+  const int W = M.w[k], H = M.h[k];
+  const float4* img = rgba + M.off[k];
   const float fx = u * (float)W - 0.5f, fy = v * (float)H - 0.5f;
   const float x0f = floorf(fx), y0f = floorf(fy);
   const float ax = fx - x0f, ay = fy - y0f;
   const int x0 = (int)x0f, y0 = (int)y0f;
   const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
   const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
-  const float4 c00 = rgba[(size_t)ya * W + xa], c10 = rgba[(size_t)ya * W + xb];
-  const float4 c01 = rgba[(size_t)yb * W + xa], c11 = rgba[(size_t)yb * W + xb];
+  const float4 c00 = img[(size_t)ya * W + xa], c10 = img[(size_t)ya * W + xb];
+  const float4 c01 = img[(size_t)yb * W + xa], c11 = img[(size_t)yb * W + xb];
   auto lerp2 = [&](float p00, float p10, float p01, float p11) {
     const float top = p00 * (1.0f - ax) + p10 * ax, bot = p01 * (1.0f - ax) + p11 * ax;
     return top * (1.0f - ay) + bot * ay;
@@ -2213,9 +2237,97 @@ __device__ __forceinline__ float4 canopy_sample(const float4* __restrict__ rgba,
   return make_float4(lerp2(c00.x, c10.x, c01.x, c11.x), lerp2(c00.y, c10.y, c01.y, c11.y),
                      lerp2(c00.z, c10.z, c01.z, c11.z), lerp2(c00.w, c10.w, c01.w, c11.w));
 }
+// texture(sampler, texVar) as the reference asks OpenGL for it (source/gpu/GlUtil.h:316-338: mipmaps,
+// GL_LINEAR_MIPMAP_LINEAR, maximum anisotropy), following EXT_texture_filter_anisotropic: N = min(ceil(Pmax / Pmin),
+// 16) trilinear taps along the major axis of the pixel footprint, LOD from Pmax / N. The LOD fraction is linear in
+// the footprint inside an octave (frexp, no log2), which keeps it exact in fp32. (ax, ay) = dFdx(texVar),
+// (bx, by) = dFdy(texVar), normalised texture coordinates.
+__device__ __forceinline__ float4 canopy_sample(const float4* __restrict__ rgba, const CanopyMips& M, float u, float v,
+                                                float ax, float ay, float bx, float by) {
+  const float axT = ax * (float)M.w[0], ayT = ay * (float)M.h[0], bxT = bx * (float)M.w[0], byT = by * (float)M.h[0];
+  const float px2 = axT * axT + ayT * ayT, py2 = bxT * bxT + byT * byT;
+  const bool xMajor = px2 >= py2;
+  const float pMax = sqrtf(xMajor ? px2 : py2), pMin = sqrtf(xMajor ? py2 : px2);
+  if (!(pMax > 0.0f) || !isfinite(pMax)) {
+    return canopy_bilinear(rgba, M, 0, u, v);
+  }
+  int n = kCanopyMaxAniso;
+  if (pMin > 0.0f) {
+    const float r = ceilf(pMax / pMin);
+    n = r < (float)kCanopyMaxAniso ? (int)r : kCanopyMaxAniso;
+  }
+  const float rho = pMax / (float)n;
+  const int top = M.n - 1;
+  int level = 0;
+  float frac = 0.0f;
+  if (rho > 1.0f) {
+    int e;
+    const float mant = frexpf(rho, &e);  // rho = mant * 2^e, mant in [0.5, 1)
+    level = e - 1;
+    frac = 2.0f * mant - 1.0f;
+    if (level >= top) {
+      level = top;
+      frac = 0.0f;
+    }
+  }
+  const float du = xMajor ? ax : bx, dv = xMajor ? ay : by;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int i = 1; i <= n; ++i) {
+    const float t = (float)i / (float)(n + 1) - 0.5f;
+    const float uu = u + du * t, vv = v + dv * t;
+    float4 a = canopy_bilinear(rgba, M, level, uu, vv);
+    if (frac > 0.0f) {
+      const float4 b = canopy_bilinear(rgba, M, level + 1, uu, vv);
+      a = make_float4(a.x * (1.0f - frac) + b.x * frac, a.y * (1.0f - frac) + b.y * frac, a.z * (1.0f - frac) + b.z * frac,
+                      a.w * (1.0f - frac) + b.w * frac);
+    }
+    sum = make_float4(sum.x + a.x, sum.y + a.y, sum.z + a.z, sum.w + a.w);
+  }
+  return make_float4(sum.x / (float)n, sum.y / (float)n, sum.z / (float)n, sum.w / (float)n);
+}
+// texVar and its fine 2x2-quad derivatives at pixel (i, j) of triangle T
+__device__ __forceinline__ void canopy_grad(const CanopyTri& T, int i, int j, float& u, float& v, float& ax, float& ay,
+                                            float& bx, float& by) {
+  canopy_tex(T, i + 0.5f, j + 0.5f, u, v);
+  const int ib = i & ~1, jb = j & ~1;
+  float ua, va, ub, vb;
+  canopy_tex(T, ib + 0.5f, j + 0.5f, ua, va);
+  canopy_tex(T, ib + 1.5f, j + 0.5f, ub, vb);
+  ax = ub - ua;  // dFdx(texVar): fine derivative inside the 2x2 quad
+  ay = vb - va;
+  canopy_tex(T, i + 0.5f, jb + 0.5f, ua, va);
+  canopy_tex(T, i + 0.5f, jb + 1.5f, ub, vb);
+  bx = ub - ua;  // dFdy(texVar)
+  by = vb - va;
+}
 
-__global__ void k_canopy_raster(const float4* __restrict__ vert, const float4* __restrict__ rgba, int W, int H, float cx,
-                                float cy, float cz, int face, int E, unsigned long long* __restrict__ zbuf) {
+// depth + discard test of triangle T at face pixel (i, j): the fragment shader's `discard` needs the filtered alpha
+__device__ __forceinline__ void canopy_fragment(const CanopyTri& T, const float4* __restrict__ rgba, const CanopyMips& M,
+                                                int i, int j, int E, unsigned triId, unsigned long long* __restrict__ zbuf) {
+  float l[3];
+  if (!canopy_bary(T, i + 0.5f, j + 0.5f, l, true)) {
+    return;
+  }
+  const float iz = canopy_invz(T, l);
+  if (!(iz > 0.0f)) {
+    return;
+  }
+  float u, v, ax, ay, bx, by;
+  canopy_grad(T, i, j, u, v, ax, ay, bx, by);
+  if (canopy_sample(rgba, M, u, v, ax, ay, bx, by).w == 0.0f) {
+    return;  // discard: no colour, no depth
+  }
+  // nearer = larger 1/z; equal depth: the later triangle wins (GL_LEQUAL)
+  atomicMax(&zbuf[(size_t)j * E + i], ((unsigned long long)__float_as_uint(iz) << 32) | triId);
+}
+
+// One thread per mesh triangle. Triangles whose bounding box holds more than kCanopyBigTri face pixels (the
+// stretched triangles across depth discontinuities cover thousands) are appended to `big` and rasterised by
+// k_canopy_raster_big, one workgroup per triangle, instead of serialising one thread.
+constexpr int kCanopyBigTri = 64;
+__global__ void k_canopy_raster(const float4* __restrict__ vert, const float4* __restrict__ rgba, CanopyMips M, int W, int H,
+                                float cx, float cy, float cz, int face, int E, unsigned long long* __restrict__ zbuf,
+                                unsigned* __restrict__ big, unsigned* __restrict__ nBig) {
   const int qx = blockIdx.x * blockDim.x + threadIdx.x, qy = blockIdx.y * blockDim.y + threadIdx.y;
   const int t = blockIdx.z;
   if (qx + 1 >= W || qy + 1 >= H) {
@@ -2232,31 +2344,47 @@ __global__ void k_canopy_raster(const float4* __restrict__ vert, const float4* _
   }
   const int i0 = max(0, (int)ceilf(minx - 0.5f)), i1 = min(E - 1, (int)floorf(maxx - 0.5f));
   const int j0 = max(0, (int)ceilf(miny - 0.5f)), j1 = min(E - 1, (int)floorf(maxy - 0.5f));
+  if (i1 < i0 || j1 < j0) {
+    return;
+  }
   const unsigned triId = (unsigned)(((size_t)qy * W + qx) * 2 + t);
+  if ((long long)(i1 - i0 + 1) * (j1 - j0 + 1) > kCanopyBigTri) {
+    big[atomicAdd(nBig, 1u)] = triId;
+    return;
+  }
   for (int j = j0; j <= j1; ++j) {
     for (int i = i0; i <= i1; ++i) {
-      float l[3];
-      if (!canopy_bary(T, i + 0.5f, j + 0.5f, l, true)) {
-        continue;
-      }
-      const float iz = canopy_invz(T, l);
-      if (!(iz > 0.0f)) {
-        continue;
-      }
-      float u, v;
-      canopy_tex(T, i + 0.5f, j + 0.5f, u, v);
-      if (canopy_sample(rgba, W, H, u, v).w == 0.0f) {
-        continue;  // discard: no colour, no depth
-      }
-      // nearer = larger 1/z; equal depth: the later triangle wins (GL_LEQUAL)
-      atomicMax(&zbuf[(size_t)j * E + i], ((unsigned long long)__float_as_uint(iz) << 32) | triId);
+      canopy_fragment(T, rgba, M, i, j, E, triId, zbuf);
+    }
+  }
+}
+__global__ void __launch_bounds__(256)
+    k_canopy_raster_big(const float4* __restrict__ vert, const float4* __restrict__ rgba, CanopyMips M, int W, int H, float cx,
+                        float cy, float cz, int face, int E, unsigned long long* __restrict__ zbuf,
+                        const unsigned* __restrict__ big, const unsigned* __restrict__ nBig) {
+  const unsigned count = *nBig;
+  for (unsigned b = blockIdx.x; b < count; b += gridDim.x) {
+    const unsigned triId = big[b];
+    const int t = triId & 1, q = triId >> 1, qx = q % W, qy = q / W;
+    CanopyTri T;
+    if (!canopy_setup(vert, W, H, qx, qy, t, cx, cy, cz, face, E, T)) {
+      continue;
+    }
+    const float minx = fminf(T.sx[0], fminf(T.sx[1], T.sx[2])), maxx = fmaxf(T.sx[0], fmaxf(T.sx[1], T.sx[2]));
+    const float miny = fminf(T.sy[0], fminf(T.sy[1], T.sy[2])), maxy = fmaxf(T.sy[0], fmaxf(T.sy[1], T.sy[2]));
+    const int i0 = max(0, (int)ceilf(minx - 0.5f)), i1 = min(E - 1, (int)floorf(maxx - 0.5f));
+    const int j0 = max(0, (int)ceilf(miny - 0.5f)), j1 = min(E - 1, (int)floorf(maxy - 0.5f));
+    const int bw = i1 - i0 + 1;
+    const long long area = (long long)bw * (j1 - j0 + 1);
+    for (long long p = threadIdx.x; p < area; p += blockDim.x) {
+      canopy_fragment(T, rgba, M, i0 + (int)(p % bw), j0 + (int)(p / bw), E, triId, zbuf);
     }
   }
 }
 
-__global__ void k_canopy_resolve(const float4* __restrict__ vert, const float4* __restrict__ rgba, int W, int H, float cx,
-                                 float cy, float cz, int face, int E, const unsigned long long* __restrict__ zbuf,
-                                 float4* __restrict__ acc) {
+__global__ void k_canopy_resolve(const float4* __restrict__ vert, const float4* __restrict__ rgba, CanopyMips M, int W, int H,
+                                 float cx, float cy, float cz, int face, int E,
+                                 const unsigned long long* __restrict__ zbuf, float4* __restrict__ acc) {
   __shared__ unsigned long long expTab[32];
   {
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
@@ -2277,17 +2405,9 @@ __global__ void k_canopy_resolve(const float4* __restrict__ vert, const float4* 
   const int t = triId & 1, q = triId >> 1, qx = q % W, qy = q / W;
   CanopyTri T;
   canopy_setup(vert, W, H, qx, qy, t, cx, cy, cz, face, E, T);
-  float u, v;
-  canopy_tex(T, i + 0.5f, j + 0.5f, u, v);
-  const float4 c = canopy_sample(rgba, W, H, u, v);
-  const int ib = i & ~1, jb = j & ~1;
-  float ua, va, ub, vb;
-  canopy_tex(T, ib + 0.5f, j + 0.5f, ua, va);
-  canopy_tex(T, ib + 1.5f, j + 0.5f, ub, vb);
-  const float ax = ub - ua, ay = vb - va;  // dFdx(texVar): fine derivative inside the 2x2 quad
-  canopy_tex(T, i + 0.5f, jb + 0.5f, ua, va);
-  canopy_tex(T, i + 0.5f, jb + 1.5f, ub, vb);
-  const float bx = ub - ua, by = vb - va;  // dFdy(texVar)
+  float u, v, ax, ay, bx, by;
+  canopy_grad(T, i, j, u, v, ax, ay, bx, by);
+  const float4 c = canopy_sample(rgba, M, u, v, ax, ay, bx, by);
   const float aa = ax * ax + ay * ay, bb = bx * bx + by * by, ab = ax * bx + ay * by;
   const float hx = (aa - bb) / 2.0f;
   const float minor = (aa + bb) / 2.0f - sqrtf(hx * hx + ab * ab);

@@ -11,9 +11,12 @@
 // What OpenGL leaves to the implementation is fixed here as follows: pixel centres at half
 // integers with an inclusive edge test (no holes; double hits resolve through the depth test, later triangle
 // wins ties like GL_LEQUAL); triangles with a vertex nearer than the near plane (0.1 m) or with a NaN vertex
-// are dropped instead of clipped; derivatives are the fine 2x2-quad differences of the winning triangle's
-// perspective-correct interpolant; the texture is sampled bilinearly at level 0 (cube faces magnify the camera
-// images; the reference asks for trilinear + anisotropic filtering, whose result is driver-defined). fp32
+// are dropped instead of clipped; derivatives are the fine 2x2-quad differences of the triangle's
+// perspective-correct interpolant; the texture is filtered the way the reference asks OpenGL to
+// (source/gpu/GlUtil.h:316-338: glGenerateMipmap, GL_LINEAR_MIPMAP_LINEAR, maximum anisotropy): a 2x2-box mip
+// chain, and per fragment the EXT_texture_filter_anisotropic recipe — N = min(ceil(Pmax / Pmin), 16) trilinear taps
+// along the major axis of the pixel footprint at LOD log2(Pmax / N) — with the LOD fraction taken linear in the
+// footprint inside an octave (no log2: exact in fp32, so HIP and this restatement agree bit for bit). fp32
 // throughout, like the shaders; the mesh vertices come from the fp64 camera model and are rounded to fp32
 // (cv::Vec3f). Test infrastructure only.
 #pragma once
@@ -36,11 +39,43 @@ static const int kCubeAxes[6][3][2] = {  // {axis index 0..2, sign}
     {{0, +1}, {2, -1}, {1, -1}}, {{0, -1}, {2, +1}, {1, -1}}, {{1, +1}, {0, +1}, {2, +1}},
     {{1, -1}, {0, +1}, {2, -1}}, {{2, +1}, {0, +1}, {1, -1}}, {{2, -1}, {0, -1}, {1, -1}}};
 
+static const int kCanopyMaxAniso = 16;  // GL_MAX_TEXTURE_MAX_ANISOTROPY of current hardware
+
 struct CanopyMesh {
   int w = 0, h = 0;
   std::vector<float> v;        // [h][w][3] rig-space vertex, NaN when the disparity is unusable
-  std::vector<float> rgba;     // [h][w][4] B, G, R in [0, 1], A = inside the image circle
+  std::vector<float> rgba;     // mip chain, level 0 first: [h_k][w_k][4] B, G, R in [0, 1], A = inside the image circle
+  std::vector<size_t> mipOff;  // float offset of each level in rgba
+  std::vector<int> mipW, mipH;
 };
+
+// glGenerateMipmap: level k = 2x2 box of level k - 1 (sizes halve, rounding down, never below 1; an odd last
+// row / column repeats its edge texel)
+static inline void canopyBuildMips(CanopyMesh& m) {
+  m.mipOff.assign(1, 0);
+  m.mipW.assign(1, m.w);
+  m.mipH.assign(1, m.h);
+  while (m.mipW.back() > 1 || m.mipH.back() > 1) {
+    const int sw = m.mipW.back(), sh = m.mipH.back();
+    const int dw = std::max(1, sw >> 1), dh = std::max(1, sh >> 1);
+    const size_t so = m.mipOff.back(), dofs = m.rgba.size();
+    m.rgba.resize(dofs + (size_t)dw * dh * 4);
+    for (int y = 0; y < dh; ++y) {
+      for (int x = 0; x < dw; ++x) {
+        const int x0 = std::min(2 * x, sw - 1), x1 = std::min(2 * x + 1, sw - 1);
+        const int y0 = std::min(2 * y, sh - 1), y1 = std::min(2 * y + 1, sh - 1);
+        for (int c = 0; c < 4; ++c) {
+          const float a = m.rgba[so + ((size_t)y0 * sw + x0) * 4 + c], b = m.rgba[so + ((size_t)y0 * sw + x1) * 4 + c];
+          const float e = m.rgba[so + ((size_t)y1 * sw + x0) * 4 + c], f = m.rgba[so + ((size_t)y1 * sw + x1) * 4 + c];
+          m.rgba[dofs + ((size_t)y * dw + x) * 4 + c] = ((a + b) + (e + f)) * 0.25f;
+        }
+      }
+    }
+    m.mipOff.push_back(dofs);
+    m.mipW.push_back(dw);
+    m.mipH.push_back(dh);
+  }
+}
 
 static inline CanopyMesh canopyMesh(const Camera& cam, const uint16_t* bgr, const float* disp, int w, int h) {
   CanopyMesh m;
@@ -66,6 +101,7 @@ static inline CanopyMesh canopyMesh(const Camera& cam, const uint16_t* bgr, cons
       m.rgba[4 * i + 3] = cam.isOutsideImageCircle(p) ? 0.0f : 1.0f;  // alphaFov, CanopyScene.cpp:465-476
     }
   }
+  canopyBuildMips(m);
   return m;
 }
 
@@ -117,20 +153,90 @@ static inline void canopyTex(const CanopyTri& T, float px, float py, float& u, f
   u = (l[0] * (T.tu[0] * T.invd[0]) + l[1] * (T.tu[1] * T.invd[1]) + l[2] * (T.tu[2] * T.invd[2])) / iz;
   v = (l[0] * (T.tv[0] * T.invd[0]) + l[1] * (T.tv[1] * T.invd[1]) + l[2] * (T.tv[2] * T.invd[2])) / iz;
 }
-// GL_LINEAR at level 0, clamp to edge; out = B, G, R, A
-static inline void canopySample(const CanopyMesh& m, float u, float v, float out[4]) {
-  const float fx = u * (float)m.w - 0.5f, fy = v * (float)m.h - 0.5f;
+// GL_LINEAR inside mip level `k`, clamp to edge; out = B, G, R, A
+static inline void canopyBilinear(const CanopyMesh& m, int k, float u, float v, float out[4]) {
+  const int w = m.mipW[k], h = m.mipH[k];
+  const float* img = m.rgba.data() + m.mipOff[k];
+  const float fx = u * (float)w - 0.5f, fy = v * (float)h - 0.5f;
   const float x0f = std::floor(fx), y0f = std::floor(fy);
   const float ax = fx - x0f, ay = fy - y0f;
   const int x0 = (int)x0f, y0 = (int)y0f;
-  const int xa = std::min(std::max(x0, 0), m.w - 1), xb = std::min(std::max(x0 + 1, 0), m.w - 1);
-  const int ya = std::min(std::max(y0, 0), m.h - 1), yb = std::min(std::max(y0 + 1, 0), m.h - 1);
+  const int xa = std::min(std::max(x0, 0), w - 1), xb = std::min(std::max(x0 + 1, 0), w - 1);
+  const int ya = std::min(std::max(y0, 0), h - 1), yb = std::min(std::max(y0 + 1, 0), h - 1);
   for (int c = 0; c < 4; ++c) {
-    const float c00 = m.rgba[((size_t)ya * m.w + xa) * 4 + c], c10 = m.rgba[((size_t)ya * m.w + xb) * 4 + c];
-    const float c01 = m.rgba[((size_t)yb * m.w + xa) * 4 + c], c11 = m.rgba[((size_t)yb * m.w + xb) * 4 + c];
+    const float c00 = img[((size_t)ya * w + xa) * 4 + c], c10 = img[((size_t)ya * w + xb) * 4 + c];
+    const float c01 = img[((size_t)yb * w + xa) * 4 + c], c11 = img[((size_t)yb * w + xb) * 4 + c];
     const float top = c00 * (1.0f - ax) + c10 * ax, bot = c01 * (1.0f - ax) + c11 * ax;
     out[c] = top * (1.0f - ay) + bot * ay;
   }
+}
+
+// texture(sampler, texVar) under GL_LINEAR_MIPMAP_LINEAR + maximum anisotropy; (ax, ay) = dFdx(texVar),
+// (bx, by) = dFdy(texVar), in normalised texture coordinates
+static inline void canopySample(const CanopyMesh& m, float u, float v, float ax, float ay, float bx, float by, float out[4]) {
+  const float axT = ax * (float)m.w, ayT = ay * (float)m.h, bxT = bx * (float)m.w, byT = by * (float)m.h;
+  const float px2 = axT * axT + ayT * ayT, py2 = bxT * bxT + byT * byT;
+  const bool xMajor = px2 >= py2;
+  const float pMax = std::sqrt(xMajor ? px2 : py2), pMin = std::sqrt(xMajor ? py2 : px2);
+  if (!(pMax > 0.0f) || !std::isfinite(pMax)) {
+    canopyBilinear(m, 0, u, v, out);
+    return;
+  }
+  int n = kCanopyMaxAniso;
+  if (pMin > 0.0f) {
+    const float r = std::ceil(pMax / pMin);
+    n = r < (float)kCanopyMaxAniso ? (int)r : kCanopyMaxAniso;
+  }
+  const float rho = pMax / (float)n;
+  const int top = (int)m.mipW.size() - 1;
+  int level = 0;
+  float frac = 0.0f;
+  if (rho > 1.0f) {
+    int e;
+    const float mant = std::frexp(rho, &e);  // rho = mant * 2^e, mant in [0.5, 1)
+    level = e - 1;
+    frac = 2.0f * mant - 1.0f;
+    if (level >= top) {
+      level = top;
+      frac = 0.0f;
+    }
+  }
+  const float du = xMajor ? ax : bx, dv = xMajor ? ay : by;
+  float sum[4] = {0, 0, 0, 0};
+  for (int i = 1; i <= n; ++i) {
+    const float t = (float)i / (float)(n + 1) - 0.5f;
+    const float uu = u + du * t, vv = v + dv * t;
+    float a[4], b[4];
+    canopyBilinear(m, level, uu, vv, a);
+    if (frac > 0.0f) {
+      canopyBilinear(m, level + 1, uu, vv, b);
+      for (int c = 0; c < 4; ++c) {
+        a[c] = a[c] * (1.0f - frac) + b[c] * frac;
+      }
+    }
+    for (int c = 0; c < 4; ++c) {
+      sum[c] += a[c];
+    }
+  }
+  for (int c = 0; c < 4; ++c) {
+    out[c] = sum[c] / (float)n;
+  }
+}
+
+// texVar and its fine 2x2-quad derivatives at pixel (i, j) of triangle T
+static inline void canopyGrad(const CanopyTri& T, int i, int j, float& u, float& v, float& ax, float& ay, float& bx,
+                              float& by) {
+  canopyTex(T, i + 0.5f, j + 0.5f, u, v);
+  const int ib = i & ~1, jb = j & ~1;
+  float ua, va, ub, vb;
+  canopyTex(T, ib + 0.5f, j + 0.5f, ua, va);
+  canopyTex(T, ib + 1.5f, j + 0.5f, ub, vb);
+  ax = ub - ua;  // dFdx(texVar)
+  ay = vb - va;
+  canopyTex(T, i + 0.5f, jb + 0.5f, ua, va);
+  canopyTex(T, i + 0.5f, jb + 1.5f, ub, vb);
+  bx = ub - ua;  // dFdy(texVar)
+  by = vb - va;
 }
 
 // cameras `include[s] != 0` rendered from `centre` -> BGRA float [6 * E][E]
@@ -179,9 +285,9 @@ static inline void canopyCubemap(const Rig& rig, const uint16_t* const* colors, 
                 if (!(iz > 0.0f)) {
                   continue;
                 }
-                float u, v, c[4];
-                canopyTex(T, i + 0.5f, j + 0.5f, u, v);
-                canopySample(m, u, v, c);
+                float u, v, ax, ay, bx, by, c[4];
+                canopyGrad(T, i, j, u, v, ax, ay, bx, by);
+                canopySample(m, u, v, ax, ay, bx, by, c);
                 if (c[3] == 0.0f) {
                   continue;  // discard: no colour, no depth
                 }
@@ -206,17 +312,9 @@ static inline void canopyCubemap(const Rig& rig, const uint16_t* const* colors, 
           const int t = triId & 1, q = triId >> 1, qx = q % w, qy = q / w;
           CanopyTri T;
           canopySetup(m, qx, qy, t, centre, face, E, T);
-          float u, v, c[4];
-          canopyTex(T, i + 0.5f, j + 0.5f, u, v);
-          canopySample(m, u, v, c);
-          const int ib = i & ~1, jb = j & ~1;
-          float ua, va, ub, vb;
-          canopyTex(T, ib + 0.5f, j + 0.5f, ua, va);
-          canopyTex(T, ib + 1.5f, j + 0.5f, ub, vb);
-          const float ax = ub - ua, ay = vb - va;  // dFdx(texVar)
-          canopyTex(T, i + 0.5f, jb + 0.5f, ua, va);
-          canopyTex(T, i + 0.5f, jb + 1.5f, ub, vb);
-          const float bx = ub - ua, by = vb - va;  // dFdy(texVar)
+          float u, v, ax, ay, bx, by, c[4];
+          canopyGrad(T, i, j, u, v, ax, ay, bx, by);
+          canopySample(m, u, v, ax, ay, bx, by, c);
           const float aa = ax * ax + ay * ay, bb = bx * bx + by * by, ab = ax * bx + ay * by;
           const float hx = (aa - bb) / 2.0f;
           const float minor = (aa + bb) / 2.0f - std::sqrt(hx * hx + ab * ab);

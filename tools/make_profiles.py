@@ -12,10 +12,25 @@ chip. GRBM_GUI_ACTIVE counts cycles and is summed over the 8 XCDs (checked: valu
 (the finest level is by far the biggest launch of a kernel).
 usage: tools/make_profiles.py <tag> <config>"""
 import csv
+import hashlib
 import json
 import os
 import shutil
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KERNEL_SOURCES = ("derp_kernels.h", "derp_capi.hip", "derp_camera.h", "gcc_algos.h", "derp_sequence.h")
+
+
+def kernel_sources_sha256():
+    """Hash of the translation unit the counters were collected on; bench.py refuses to combine them with the
+    timings of other sources."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "facebook360_dep_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
@@ -78,6 +93,14 @@ def kernel_view(kernel):
             out["chip_busy_cycles_per_launch"] = busy
     i = lambda c: val("SQ_INSTS", kernel, c, "max")  # noqa: E731
     if i("SQ_INSTS_VALU"):
+        # second numerator: VALU wave-instructions x 4 cycles (the issue time of a 64-lane instruction on a 16-lane
+        # pipe). SQ_ACTIVE_INST_VALU (above) is summed over WAVES: with three or more resident waves per SIMD two of
+        # them can have an instruction in the pipe in the same cycle, which is how a "busy fraction" above 1 arises
+        # for kernels like k_joint_bilateral — both are upper estimates of pipe occupancy there, and neither prices
+        # the 8- / 16-pass instructions (fp64 transcendentals, packed fp32) at their true cost.
+        out["valu_insts_x4_cycles_per_launch"] = 4.0 * i("SQ_INSTS_VALU")
+        if gui:
+            out["valu_insts_x4_frac"] = round(4.0 * i("SQ_INSTS_VALU") / (N_SIMD * gui / N_XCD), 4)
         out["insts_per_launch"] = {"valu": i("SQ_INSTS_VALU"), "salu": i("SQ_INSTS_SALU"), "lds": i("SQ_INSTS_LDS"),
                                    "vmem_rd": i("SQ_INSTS_VMEM_RD")}
         out["lds_bank_conflict_over_idx_active"] = round(i("SQ_LDS_BANK_CONFLICT") / max(i("SQ_LDS_IDX_ACTIVE"), 1.0), 4)
@@ -89,11 +112,14 @@ path = os.path.join(dst, "valu_roofline.json")
 tr = json.load(open(path)) if os.path.exists(path) else {}
 pp = kernel_view("k_ping_pong(")
 entry = {
+    "kernel_sources_sha256": kernel_sources_sha256(),
     "source": "%s_pmc_{FETCH_SIZE,WRITE_SIZE,SQ_ISSUE,SQ_INSTS}.json (rocprofv3 --pmc, one pass per group, on "
               "`bench.py --steps 1 --warmup 0`); %s_kernel_stats.csv for durations" % (tag, tag),
     "corrections": "FETCH_SIZE KB x2 (gfx950 half-count), WRITE_SIZE KB x1; SQ quad-cycles x4",
     "ping_pong_level0_valu_busy_cycles_per_launch": pp.get("valu_busy_cycles_per_launch"),
     "ping_pong_level0_valu_busy_frac": pp.get("valu_busy_frac"),
+    "ping_pong_level0_valu_insts_x4_cycles_per_launch": pp.get("valu_insts_x4_cycles_per_launch"),
+    "ping_pong_level0_waves_per_simd": pp.get("waves_per_simd_avg"),
     "ping_pong_level0_wave_cycle_shares": pp.get("wave_cycle_shares"),
     "ping_pong_level0_hbm_bytes_per_launch": pp.get("hbm_bytes_per_launch"),
     "kernels_level0_launch": {n: kernel_view(n) for n in

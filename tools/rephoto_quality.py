@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Developer tool: rephotography score (bin/ComputeRephotographyErrors) of the estimated level-0
 disparity against the score the analytic ground-truth disparity gets on the same synthetic rig."""
-import os, subprocess, sys, tempfile
+import os, subprocess, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from facebook360_dep_amd import synth, imageio as dio
@@ -24,9 +24,11 @@ for cam, t in zip(rig["cameras"], frame["truth"]):
     fov = np.isfinite(dio.read_pfm(os.path.join(out, "disparity_levels", "level_0", cam["id"], "000000.pfm")))
     dio.write_pfm(os.path.join(truth, cam["id"], "000000.pfm"), np.where(fov, t, np.nan).astype(np.float32))
 for label, disp in (("estimated", os.path.join(out, "disparity_levels", "level_0")), ("ground truth", truth)):
+    t0 = time.time()
     p = subprocess.run([os.path.join(BIN, "ComputeRephotographyErrors"), "--first=000000", "--last=000000",
                         "--output=" + os.path.join(root, "rephoto_" + label.split()[0]),
                         "--rig=" + os.path.join(root, "rigs", "rig_calibrated.json"),
                         "--color=" + os.path.join(root, "video", "color_levels", "level_0"), "--disparity=" + disp],
                        capture_output=True, text=True, check=True)
-    print(name, label, "disparity:", p.stderr.strip().splitlines()[-1].split("] ")[-1])
+    print(name, label, "disparity:", p.stderr.strip().splitlines()[-1].split("] ")[-1],
+          "(ComputeRephotographyErrors: %.1f s wall)" % (time.time() - t0))
