@@ -67,6 +67,32 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
+def usable_cpus():
+    """CPUs this process may actually burn: affinity mask and cgroup quota (a container that sees 256 hardware
+    threads may be allowed 16 CPUs' worth of time)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def b_alg(n_cost, n_pair):
     """logical gather bytes of the cost loop."""
     return 64.0 * n_cost + 272.0 * n_pair
@@ -81,8 +107,12 @@ def cpu_baseline(rig, sizes, frame, res, n_cams):
     from facebook360_dep_amd import synth
     from tests import common
 
-    cores = os.cpu_count() or 1
-    out = {"unit": "Mpix/s", "cores": cores, "kind": "port"}
+    threads = os.cpu_count() or 1
+    cores = usable_cpus()
+    out = {"unit": "Mpix/s", "cores": cores, "kind": "port",
+           "threads": threads,
+           "cores_note": "%d worker threads (one per visible hardware thread) on %d usable CPUs (scheduler affinity and "
+                         "cgroup CPU quota of this container)" % (threads, cores)}
     # --- config 1 in full (4 x 512^2, 8 levels)
     n1, r1, w1 = synth.config("cfg1")
     rig1 = synth.make_rig(n1, r1)
@@ -110,7 +140,7 @@ def cpu_baseline(rig, sizes, frame, res, n_cams):
     total = measured + extra
     w0, h0 = sizes[0]
     out["value"] = round(n_cams * w0 * h0 / total / 1e6, 4)
-    out["sample"] = ("frame 0 of the bench workload (%d cameras, %dx%d): levels %d..%d measured in %.1f s on %d threads; "
+    out["sample"] = ("frame 0 of the bench workload (%d cameras, %dx%d): levels %d..%d measured in %.1f s on %d CPUs; "
                      "levels %d..0 EXTRAPOLATED from level %d's time per pixel (+%.1f s) -> %.1f s per frame. "
                      "Not the timed workload itself: one frame, no temporal filter."
                      % (n_cams, w0, h0, len(sizes) - 1, first_measured, measured, cores, first_measured - 1,
@@ -118,6 +148,15 @@ def cpu_baseline(rig, sizes, frame, res, n_cams):
         "frame 0 of the bench workload in full: %.1f s on %d threads" % (measured, cores))
     out["extrapolated"] = first_measured > 0
     out["measured_seconds"] = round(measured, 2)
+    # the same frame run in FULL once (tools/oracle_full_frame.py, committed under profiles/): quoted beside the
+    # extrapolation so that the two can be compared
+    full = os.path.join(ROOT, "profiles", "oracle_full_frame.json")
+    if os.path.exists(full):
+        try:
+            with open(full) as f:
+                out["full_frame_measured_once"] = json.load(f)
+        except Exception:  # noqa: BLE001
+            pass
     return out
 
 

@@ -13,7 +13,7 @@
 //   projColor  [DB][S-1][H+4][W+4]  ushort4, 2-texel replicated ring
 //   projBias   [DB][S-1][H+4][W+4]  ushort4, 2-texel replicated ring
 //   disparity / cost / confidence / variance  float [.][H][W]; masks uint8
-// A wave covers an 8x8 pixel tile (a 256-thread block a 16x16 tile) so that the 64 lanes'
+// A wave covers an 8x8 pixel tile (the cost kernels run one wave per block) so that the 64 lanes'
 // gathers into one source table fall into a few neighbouring cache lines; blocks are
 // remapped so that each XCD (own L2) walks a contiguous band of tiles.
 #pragma once
@@ -41,12 +41,12 @@ namespace derp {
 #ifndef DERP_TILE_BLOCK
 #define DERP_TILE_BLOCK 4
 #endif
-// fp64 atan2 / division of the cost kernels' projection through the short routines of derp_camera.h (0 = the
-// device library's)
 // skip, per wave, the sources that face away from the wave's pixels for every candidate depth (behind_sources)
 #ifndef DERP_SOURCE_CULL
 #define DERP_SOURCE_CULL 1
 #endif
+// fp64 atan2 / division of the cost kernels' projection through the short routines of derp_camera.h (0 = the
+// device library's)
 #ifndef DERP_LEAN_PROJ
 #define DERP_LEAN_PROJ 1
 #endif

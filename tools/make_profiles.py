@@ -51,7 +51,7 @@ if body:
         w.writerow(["(non-derp kernels: torch synthetic-input rendering / copies / RCCL, outside the depth path)",
                     sum(int(r[1]) for r in other), sum(int(r[2]) for r in other), "", "", "", "", ""])
 pm = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ISSUE", "SQ_INSTS"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ISSUE", "SQ_INSTS", "L2"):
     path = os.path.join(src, "%s_pmc_%s.json" % (tag, c))
     if not os.path.exists(path):
         continue

@@ -1,11 +1,14 @@
 #!/bin/bash
 # BASELINE config 4 (24 x 4096^2, single frame, destinations batched under the table budget): bench line +
-# HBM traffic passes -> gpurun_out/r02cfg4_* (tools/make_profiles.py r02cfg4 cfg4 trims them into profiles/)
-tag=r02cfg4
+# HBM traffic passes -> gpurun_out/<tag>_* (tools/make_profiles.py <tag> cfg4 trims them into profiles/)
+tag=${1:-r03cfg4}
 ARGS="--config cfg4 --frames 1 --temporal 0 --no-cpu-baseline --no-single-frame"
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py --steps 2 --warmup 1 $ARGS > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
+rm -rf /tmp/prof_$tag
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o $tag -- python bench.py --steps 2 --warmup 1 $ARGS > /dev/null 2>&1
+cp /tmp/prof_$tag/${tag}_kernel_stats.csv gpurun_out/${tag}_kernel_stats_full.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c
   rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python bench.py --steps 1 --warmup 0 $ARGS > /dev/null 2> gpurun_out/${tag}_pmc_$c.err

@@ -6,7 +6,7 @@
 #   <tag>_pmc_<GROUP>.json           one rocprofv3 --pmc pass per counter group, summarised per kernel
 # PMC passes run `bench.py --steps 1 --warmup 0` (every kernel of the sequence once per frame); counters
 # never share a run with a trace domain.          usage: tools/profile_round.sh <tag> [bench args]
-tag=${1:-r02}; shift
+tag=${1:-r03}; shift
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python bench.py --steps 3 --warmup 1 "$@" > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
@@ -22,3 +22,5 @@ pmc FETCH_SIZE "FETCH_SIZE" "$@"
 pmc WRITE_SIZE "WRITE_SIZE" "$@"
 pmc SQ_ISSUE "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "$@"
 pmc SQ_INSTS "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU" "$@"
+# L1 <-> L2 traffic (random proposals: every lane of a wave gathers from its own cache lines)
+pmc L2 "TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum" "$@"
