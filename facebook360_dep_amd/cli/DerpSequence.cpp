@@ -42,6 +42,76 @@ static const char* kUsage = R"(
     --gpus=8
 )";
 
+// ---- the "files" transport: the plan's transfers through <output_root>/.halo (one file per (level, kind, frame,
+// receiver), written under a temporary name and renamed, removed by its reader) — the reference moves the window
+// frames of TemporalBilateralFilter the same way, through the shared file system (pipeline.py:364-408)
+struct FileTransport {
+  derp_seq* seq;
+  derp_ctx* ctx;
+  int rank, world, first, last, radius, partition;
+  fs::path dir;
+  std::vector<derp_seq_transfer> plan;
+  std::vector<char> buf;
+  double seconds = 0;
+  uint64_t received = 0;
+  void init() {
+    const int n = derp_seq_plan(first, last, world, radius, partition, nullptr, 0);
+    plan.resize(std::max(n, 0));
+    if (n > 0) {
+      derp_seq_plan(first, last, world, radius, partition, plan.data(), n);
+    }
+    fs::create_directories(dir);
+  }
+  fs::path name(int level, int kind, const derp_seq_transfer& t) const {
+    return dir / fmt("L%d_k%d_f%06d_to%d.bin", level, kind, t.frame, t.to_rank);
+  }
+  void move(int level, int kind) {
+    Timer tm;
+    for (const derp_seq_transfer& t : plan) {
+      if (t.from_rank != rank) {
+        continue;
+      }
+      void* p;
+      size_t bytes;
+      DERP_OK(ctx, derp_seq_buffer(seq, t.frame, level, kind, &p, &bytes));
+      buf.resize(bytes);
+      DERP_OK(ctx, derp_seq_buffer_copy(seq, t.frame, level, kind, buf.data(), bytes, 0));
+      const fs::path dst = name(level, kind, t), tmp = dst.string() + ".tmp";
+      {
+        std::ofstream f(tmp, std::ios::binary);
+        f.write(buf.data(), (std::streamsize)bytes);
+        CHECK_MSG(f.good(), "failed to write " + tmp.string());
+      }
+      fs::rename(tmp, dst);
+    }
+    for (const derp_seq_transfer& t : plan) {
+      if (t.to_rank != rank) {
+        continue;
+      }
+      void* p;
+      size_t bytes;
+      DERP_OK(ctx, derp_seq_buffer(seq, t.frame, level, kind, &p, &bytes));
+      const fs::path src = name(level, kind, t);
+      Timer w;
+      std::error_code ec;
+      while (!fs::exists(src, ec)) {
+        CHECK_MSG(w.s() < 600, "timed out waiting for " + src.string());
+        usleep(2000);
+      }
+      buf.resize(bytes);
+      {
+        std::ifstream f(src, std::ios::binary);
+        f.read(buf.data(), (std::streamsize)bytes);
+        CHECK_MSG(f.gcount() == (std::streamsize)bytes, "short read from " + src.string());
+      }
+      fs::remove(src, ec);
+      DERP_OK(ctx, derp_seq_buffer_copy(seq, t.frame, level, kind, buf.data(), bytes, 1));
+      received += bytes;
+    }
+    seconds += tm.s();
+  }
+};
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
@@ -63,6 +133,10 @@ int main(int argc, char** argv) {
   F.i32("gpus", 1, "fork one process per GPU of this node (1 = this process only) [extension]");
   F.str("partition", "block", "frames per rank: block (contiguous chunks) | cyclic [extension]");
   F.str("rccl_id_file", "", "file through which rank 0 hands the RCCL unique id to the other ranks [extension]");
+  F.str("exchange", "rccl",
+        "how ranks move the halo frames: rccl (send / recv over xGMI) | files (through --output_root, the way the "
+        "reference's workers hand frames over; also what rccl falls back to when the communicator cannot be built, "
+        "e.g. two ranks on one GPU) [extension]");
   F.i32("resident_frames", 0,
         "frames kept in HBM per GPU: 0 = all of them; N >= 2 * time_radius + 1 = out of core, the other frames stream "
         "level by level from host memory [extension]");
@@ -156,7 +230,8 @@ int main(int argc, char** argv) {
   }
 
   const double tHost = total.s();
-  J.setup_device(world > 1 ? (localRank >= 0 ? localRank : rank) : -1);
+  // DERP_SINGLE_DEVICE: every rank on --device (several ranks sharing one GPU: tests on a one-GPU box)
+  J.setup_device(world > 1 && !getenv("DERP_SINGLE_DEVICE") ? (localRank >= 0 ? localRank : rank) : -1);
   const double tDevice = total.s();
   J.create_output_dirs({"disparity_time_filtered_levels"});
   derp_ctx* ctx = J.ctx;
@@ -182,7 +257,9 @@ int main(int argc, char** argv) {
   LOG_INFO(fmt("rank %d of %d: %d frame(s) owned, %d halo frame(s), %d frame slot(s) in HBM%s", rank, world, nOwned, nHalo,
                nSlots, nSlots < nOwned ? " (out of core)" : ""));
 
-  if (world > 1) {  // RCCL communicator: rank 0 publishes the unique id through a file
+  CHECK_MSG(F.s("exchange") == "rccl" || F.s("exchange") == "files", "exchange is rccl or files");
+  bool useFiles = world > 1 && F.s("exchange") == "files";
+  if (world > 1 && !useFiles) {  // RCCL communicator: rank 0 publishes the unique id through a file
     CHECK_MSG(!idFile.empty(), "--rccl_id_file (a path every rank can read) is needed when WORLD_SIZE > 1");
     // file = [128-byte id][nonce]: ranks started by hand (RANK / WORLD_SIZE) may find the file of an earlier job
     // under the same name; they wait until the nonce is this job's
@@ -214,11 +291,21 @@ int main(int argc, char** argv) {
         usleep(20000);
       }
     }
-    DERP_OK(ctx, derp_seq_attach_rccl(seq, id, sizeof id));
-    DERP_OK(ctx, derp_seq_selftest(seq, 4096));
+    // every rank sees the same refusal (e.g. "duplicate GPU": two ranks on one device), so every rank falls back
+    if (derp_seq_attach_rccl(seq, id, sizeof id) != 0 || derp_seq_selftest(seq, 4096) != 0) {
+      LOG_WARNING(std::string("RCCL transport unavailable (") + derp_last_error(ctx) + "); exchanging the halo frames through files");
+      useFiles = true;
+    }
     if (rank == 0 && F.i("gpus") <= 1) {
       fs::remove(idFile);  // every rank has joined the communicator: the next job must not find this id
     }
+  }
+  FileTransport files{seq, ctx, rank, world, first, last, so.do_temporal_filter ? so.time_radius : 0, partition,
+                      fs::path(J.outputRoot) / (".halo_" + std::to_string(std::hash<std::string>{}(nonce) % 100000000))};
+  if (useFiles) {
+    DERP_OK(ctx, derp_seq_attach_external(seq));
+    files.init();
+    LOG_INFO("halo exchange through files under " + files.dir.string());
   }
 
   LOG_INFO(fmt("-- start-up: flags + rig + input check %.3fs, HIP runtime + context %.3fs, output dirs + frame slots + "
@@ -251,8 +338,18 @@ int main(int argc, char** argv) {
       }
       if (world > 1) {
         DERP_OK(ctx, derp_seq_exchange_inputs_level(seq, level));  // colour guides (+ masks) of the halo frames
+        if (useFiles && so.do_temporal_filter) {
+          files.move(level, 0);
+          if (so.use_foreground_masks) {
+            files.move(level, 1);
+          }
+        }
       }
       DERP_OK(ctx, derp_seq_level_exchange(seq, level));
+      if (useFiles && so.do_temporal_filter) {
+        files.move(level, 2);
+        DERP_OK(ctx, derp_seq_mark_exchanged(seq, level));
+      }
       DERP_OK(ctx, derp_seq_level_filter(seq, level));
       DERP_OK(ctx, derp_synchronize(ctx));
       tCompute += t.s();
@@ -266,6 +363,11 @@ int main(int argc, char** argv) {
     LOG_INFO(fmt("-- Elapsed time: %.3fs wall (level %d)", total.s(), level));
   }
   writer.finish();
+  if (useFiles) {
+    std::error_code ec;
+    fs::remove(files.dir, ec);  // empty by now (every file is removed by its reader); ranks race harmlessly
+    LOG_INFO(fmt("-- rank %d: halo exchange through files: %.1f MB received, %.3fs", rank, files.received / 1e6, files.seconds));
+  }
   uint64_t sent = 0, received = 0;
   double exchangeMs = 0;
   derp_seq_stats(seq, &sent, &received, &exchangeMs);

@@ -637,6 +637,23 @@ int derp_seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, siz
   return seq_buffer(q, frame, level, kind, ptr, bytes);
 }
 
+int derp_seq_buffer_copy(derp_seq* q, int frame, int level, int kind, void* host, size_t bytes, int to_device) {
+  if (!q || !host) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  void* p;
+  size_t sz;
+  TRY(seq_buffer(q, frame, level, kind, &p, &sz));
+  if (bytes != sz) {
+    return fail(c, "buffer of frame %d level %d kind %d holds %zu bytes, not %zu", frame, level, kind, sz, bytes);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the level's kernels wrote / will read it on the library's stream
+  HIPCHK(c, hipMemcpy(to_device ? p : host, to_device ? host : p, sz, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+  return 0;
+}
+
 int derp_seq_attach_loopback(derp_seq* q, derp_seq* const* peers, int n) {
   if (!q || !peers || n != q->world) {
     return q ? fail(q->c, "loopback needs one derp_seq per rank (%d given, world %d)", n, q->world) : 1;

@@ -310,6 +310,8 @@ int derp_seq_download_disparity(derp_seq* seq, int frame, int level, int dst, fl
 /* buffer of an owned or halo frame: kind 0 colour [S][h*w] BGRX u16, 1 fg mask [S][h*w] u8,
  * 2 level disparity [D][h*w] f32 */
 int derp_seq_buffer(derp_seq* seq, int frame, int level, int kind, void** ptr, size_t* bytes);
+/* external transports that stage through host memory: copy such a buffer to (to_device = 0) or from (1) `host` */
+int derp_seq_buffer_copy(derp_seq* seq, int frame, int level, int kind, void* host, size_t bytes, int to_device);
 /* transports */
 int derp_rccl_unique_id(void* out128, size_t cap);         /* ncclGetUniqueId; rank 0 calls, caller distributes */
 int derp_seq_attach_rccl(derp_seq* seq, const void* unique_id, size_t bytes);

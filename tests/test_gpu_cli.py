@@ -29,8 +29,8 @@ def dataset(built, tmp_path_factory):
     return dict(root=root, rig=rig, sizes=sizes, res=res, n=n, frames=frames)
 
 
-def run(binary, *flags, expect_ok=True):
-    p = subprocess.run([os.path.join(BIN, binary)] + list(flags), capture_output=True, text=True, timeout=600)
+def run(binary, *flags, expect_ok=True, env=None):
+    p = subprocess.run([os.path.join(BIN, binary)] + list(flags), capture_output=True, text=True, timeout=600, env=env)
     if expect_ok:
         assert p.returncode == 0, p.stderr[-3000:]
     return p
@@ -282,6 +282,34 @@ def test_derp_sequence_cli_masks_subset_and_resume(dataset, tmp_path):
                 want = ref.disp[f][level][d].numpy()
                 assert common.compare_disparity(got, want, 1e-4)[0] == 0, (level, cam, f)
     assert sorted(os.listdir(os.path.join(out, "disparity_levels", "level_0"))) == ["cam0", "cam2"]
+
+
+def test_derp_sequence_two_processes_exchange_through_files(dataset, tmp_path):
+    """bin/DerpSequence --gpus 2 as two OS processes sharing the one GPU (DERP_SINGLE_DEVICE): the frames are
+    partitioned, the halo frames' colour guides and raw level disparities move between the processes — through
+    files (--exchange=files), and through the same files when the RCCL communicator cannot be built (RCCL refuses
+    two ranks on one device: the default --exchange=rccl must notice, say so and fall back) — and every output
+    file equals the single-process run's byte for byte."""
+    root = dataset["root"]
+    ids = [c["id"] for c in dataset["rig"]["cameras"]]
+    n_levels = len(dataset["sizes"])
+    flags = ["--input_root=" + root, "--first=000000", "--last=000002", "--partial_coverage", "--resolution=96"]
+    one = str(tmp_path / "one")
+    run("DerpSequence", *flags, "--output_root=" + one)
+    env = dict(os.environ, DERP_SINGLE_DEVICE="1")
+    for name, extra, expect in (("files", ["--exchange=files"], "halo exchange through files"),
+                                ("fallback", [], "RCCL transport unavailable")):
+        out = str(tmp_path / name)
+        p = run("DerpSequence", *flags, "--output_root=" + out, "--gpus=2", *extra, env=env)
+        assert expect in p.stderr and "2 frame(s) owned, 1 halo frame(s)" in p.stderr and \
+            "1 frame(s) owned, 2 halo frame(s)" in p.stderr, p.stderr[-3000:]
+        for kind in ("disparity_levels", "disparity_time_filtered_levels"):
+            for level in range(n_levels):
+                for cam in ids:
+                    for f in range(3):
+                        rel = os.path.join(kind, "level_%d" % level, cam, "%06d.pfm" % f)
+                        assert open(os.path.join(out, rel), "rb").read() == open(os.path.join(one, rel), "rb").read(), (name, rel)
+        assert not [d for d in os.listdir(out) if d.startswith(".halo")]
 
 
 def test_derp_sequence_failing_rank_takes_the_job_down(dataset, tmp_path):
