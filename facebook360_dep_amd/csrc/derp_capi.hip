@@ -124,6 +124,7 @@ struct derp_ctx {
   int DB = 0;  // dst batch that fits the table budget
   DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask, pairCount;
   DevBuf projWarp, projColor, projBias, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
+  DevBuf rayDir, behind;  // per destination pixel: ray direction [3][D][n] f64, sources facing away [D][n] (k_pixel_rays)
   int warpCachedLevel = -1;
   bool randomRanThisLevel = false;  // cost / confidence hold random-proposal results for this level
   bool tablesValid = false;
@@ -249,6 +250,9 @@ LevelView make_view(derp_ctx* c, int stage, int dst0, int nd) {
   V.ownBias = c->ownBias.as<ushort4>();
   V.srcVar = c->srcVar.as<float>();
   V.srcFg = c->pyrFg[L].as<uint8_t>();
+  V.rayDir = c->rayDir.as<double>();
+  V.behind = c->behind.as<unsigned>();
+  V.rayStride = (size_t)c->D * V.W * V.H;
   V.projWarp = c->projWarp.as<float2>();
   V.projColor = c->projColor.as<ushort4>();
   V.projBias = c->projBias.as<ushort4>();
@@ -510,9 +514,18 @@ int compute_fov_and_masks(derp_ctx* c, int level) {
 int build_warp(derp_ctx* c, int dst0, int nd) {
   const int L = c->cur;
   Span sp(c, ST_PROJ_WARP, L);
+  {
+    const size_t n = (size_t)c->LW[L] * c->LH[L];
+    ALLOC(c, c->rayDir, 3 * n * c->D * sizeof(double));
+    ALLOC(c, c->behind, n * c->D * sizeof(unsigned));
+  }
   LevelView V = make_view(c, ST_PROJ_WARP, dst0, nd);
   hipLaunchKernelGGL(k_proj_warp, grid2d(V.W + 2 * kPadW, V.H + 2 * kPadW, c->S, kBlk2d), kBlk2d, 0, c->stream, V,
                      c->projWarp.as<float2>());
+  KCHECK(c);
+  // the destination pixels' ray directions and behind-the-camera source masks: rig + level size only, like the warps
+  hipLaunchKernelGGL(k_pixel_rays, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->rayDir.as<double>(),
+                     c->behind.as<unsigned>());
   KCHECK(c);
   return 0;
 }
@@ -1058,7 +1071,7 @@ void derp_destroy(derp_ctx* c) {
   c->devMask.release();
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
                     &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
-                    &c->projWarp, &c->projColor, &c->projBias, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
+                    &c->projWarp, &c->projColor, &c->projBias, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
   }

@@ -76,6 +76,9 @@ struct LevelView {
   const ushort4* ownBias;     // [S][H*W]
   const float* srcVar;        // [S][H*W]
   const uint8_t* srcFg;       // [S][H*W]
+  const double* rayDir;       // [3][Dtotal][H*W] dst ray direction per pixel, planar (k_pixel_rays)
+  const unsigned* behind;     // [Dtotal][H*W] slots of the sources that face away from the pixel's ray
+  size_t rayStride;           // Dtotal * H * W
   const float2* projWarp;     // [D][S-1] padded
   const ushort4* projColor;
   const ushort4* projBias;
@@ -421,18 +424,28 @@ __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx&
 // On the 16-camera rig 8-9 of the 15 sources face away from any given tile: their per-candidate cone tests (and
 // the scalar-cache round trip for their constants) were ~5 % of the ping-pong kernel.
 static constexpr double kCullMinDepth = 0.05;  // m; candidates nearer than this (disparity > 20) take the full loop
-__device__ __forceinline__ unsigned behind_sources(const LevelView& V, int own, const PixCtx& px) {
-  unsigned cull = 0;
+__device__ __forceinline__ unsigned behind_mask(const LevelView& V, int own, const D3& rayO, const D3& rayD) {
+  unsigned m = 0;
   for (int s = 0; s < V.S; ++s) {
     if (s == own) {
       continue;
     }
     const Cam& cs = V.camsSrc[s];
-    const double a = sum3(cs.R[6] * (px.rayO.x - cs.pos[0]), cs.R[7] * (px.rayO.y - cs.pos[1]), cs.R[8] * (px.rayO.z - cs.pos[2]));
-    const double b = sum3(cs.R[6] * px.rayD.x, cs.R[7] * px.rayD.y, cs.R[8] * px.rayD.z);
-    const bool behind = cs.cos_fov >= 0 && b > 1e-6 && a + kCullMinDepth * b > 1e-6;
-    if (__ballot(!behind) == 0ull) {
-      cull |= 1u << slot(s, own);
+    const double a = sum3(cs.R[6] * (rayO.x - cs.pos[0]), cs.R[7] * (rayO.y - cs.pos[1]), cs.R[8] * (rayO.z - cs.pos[2]));
+    const double b = sum3(cs.R[6] * rayD.x, cs.R[7] * rayD.y, cs.R[8] * rayD.z);
+    if (cs.cos_fov >= 0 && b > 1e-6 && a + kCullMinDepth * b > 1e-6) {
+      m |= 1u << slot(s, own);
+    }
+  }
+  return m;
+}
+// the wave's cull mask: the sources every ACTIVE lane's pixel has behind it (per-pixel masks from k_pixel_rays)
+__device__ __forceinline__ unsigned behind_sources(const LevelView& V, int d, size_t idx) {
+  const unsigned m = V.behind[(size_t)d * ((size_t)V.W * V.H) + idx];
+  unsigned cull = 0;
+  for (int t = 0; t < V.S - 1; ++t) {
+    if (__ballot(!((m >> t) & 1u)) == 0ull) {
+      cull |= 1u << t;
     }
   }
   return __builtin_amdgcn_readfirstlane(cull);
@@ -561,10 +574,13 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
 __device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, int x, int y, PixCtx& px) {
   const Cam& cd = V.camsDst[d];
   px.rayO = {cd.pos[0], cd.pos[1], cd.pos[2]};
-  // p = ((x + .5) / W, (y + .5) / H) on the normalised camera
-  px.rayD = rig_direction(cd, (x + 0.5) / (double)V.W, (y + 0.5) / (double)V.H, cd.principal[0], cd.principal[1],
-                          cd.focal[0], cd.focal[1]);
+  // the ray direction of the pixel centre (Camera::rig of p = ((x + .5) / W, (y + .5) / H): undistort's Newton
+  // iteration, sin, cos) depends on the rig and the level size only: k_pixel_rays tabulates it with the warps
   const size_t n = (size_t)V.W * V.H;
+  {
+    const size_t i = (size_t)d * n + (size_t)y * V.W + x;
+    px.rayD = {V.rayDir[i], V.rayDir[V.rayStride + i], V.rayDir[2 * V.rayStride + i]};
+  }
   const ushort4* col = V.srcColor + (size_t)own * n;
 #pragma unroll
   for (int ix = 0; ix < 3; ++ix) {
@@ -620,6 +636,25 @@ __global__ void k_debug_atan2_ypos(const double* __restrict__ y, const double* _
     out[i] = atan2_ypos(y[i], x[i]);
   }
 #endif
+}
+
+// Per destination pixel: the rig-space ray direction of its centre (dstToWorldPoint's Camera::rig, DerpUtil.cpp:38-52,
+// Camera.h:131-138) and the slots of the sources that face away from that ray (behind_mask). Rig + level size only:
+// built with the projection warps, read by every cost kernel instead of redoing ~800 fp64 instructions per pixel.
+__global__ void k_pixel_rays(LevelView V, double* __restrict__ rays, unsigned* __restrict__ behind) {
+  const int d = V.dst0 + (int)blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= V.W || y >= V.H) {
+    return;
+  }
+  const Cam& cd = V.camsDst[d];
+  const D3 dir = rig_direction(cd, (x + 0.5) / (double)V.W, (y + 0.5) / (double)V.H, cd.principal[0], cd.principal[1],
+                               cd.focal[0], cd.focal[1]);
+  const size_t i = (size_t)d * ((size_t)V.W * V.H) + (size_t)y * V.W + x;
+  rays[i] = dir.x;
+  rays[V.rayStride + i] = dir.y;
+  rays[2 * V.rayStride + i] = dir.z;
+  behind[i] = behind_mask(V, V.dst2src[d], D3{cd.pos[0], cd.pos[1], cd.pos[2]}, dir);
 }
 
 // generateFovMasks — DerpUtil.cpp:239-276 (normalised camera: p = (x+.5, y+.5) / (W, H))
@@ -1018,7 +1053,7 @@ __global__ void k_brute_margin(LevelView V) {
 // ----------------------------------------------------------------------------------------
 // random proposals — Derp.cpp:750-873. The reference walks each row with one engine seeded
 // y * level; a pixel's draws start at numProposals * (#gated-in pixels to its left).
-// k_row_rank computes that count; k_random_proposals jumps the LCG there.
+// k_row_rank computes that count and leaves the engine's state at that position for every pixel.
 // ----------------------------------------------------------------------------------------
 __device__ __forceinline__ bool random_gate(const LevelView& V, int d, int own, size_t idx) {
   const size_t n = (size_t)V.W * V.H;
@@ -1051,10 +1086,17 @@ __global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__
     partial[threadIdx.x] += v;
     __syncthreads();
   }
-  int run = partial[threadIdx.x] - cnt;
+  // the engine's state in front of every pixel's draws: one O(log n) jump to the thread's first pixel, then one
+  // multiplication by a^P per gated-in pixel (the random-proposal kernel used to jump per pixel: ~60 dependent
+  // 64-bit multiply-reduce steps at the head of every pixel's chain)
+  const int run = partial[threadIdx.x] - cnt;
+  uint32_t state = minstd_jump(minstd_seed(y * V.level), (uint64_t)V.randomProposals * (uint64_t)run);
+  const uint32_t aP = minstd_jump(1u, (uint64_t)V.randomProposals);
   for (int x = x0; x < x1; ++x) {
-    rank[(size_t)d * n + (size_t)y * V.W + x] = run;
-    run += random_gate(V, d, own, (size_t)y * V.W + x);
+    rank[(size_t)d * n + (size_t)y * V.W + x] = (int)state;
+    if (random_gate(V, d, own, (size_t)y * V.W + x)) {
+      state = minstd_mulmod(state, aP);
+    }
   }
 }
 
@@ -1077,7 +1119,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
       } else if (random_gate(V, d, own, idx)) {
         PixCtx px;
         load_pixctx(V, d, own, x, y, px);
-        const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, own, px) : 0u;
+        const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float currDisp = disp[idx];
         unsigned before = nPair;
         float2 cur = compute_cost(V, dl, own, px, currDisp, pairs, nPair, cull);
@@ -1088,8 +1130,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
         const float minDisp = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : (1.0f / V.maxDepthM);
         const float maxDisp = 1.0f / V.minDepthM;
         float amplitude = (maxDisp - minDisp) / 2.0f;
-        uint32_t state = minstd_jump(minstd_seed(y * V.level),
-                                     (uint64_t)V.randomProposals * (uint64_t)rank[(size_t)d * n + idx]);
+        uint32_t state = (uint32_t)rank[(size_t)d * n + idx];  // minstd_rand0 positioned by k_row_rank
         for (int i = 0; i < V.randomProposals; ++i) {
           const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
           const float propDisp = minstd_uniform(state, lo, hi);
@@ -1143,7 +1184,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
       } else if (!(V.srcVar[(size_t)own * n + idx] < V.varNoiseFloor)) {
         PixCtx px;
         load_pixctx(V, d, own, x, y, px);
-        const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, own, px) : 0u;
+        const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float bestCost = __builtin_inff();
         float bestDisp = outDisp;
         const float bg = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : 0.f;
