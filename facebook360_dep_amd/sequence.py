@@ -306,7 +306,19 @@ class SequenceRunner:
         for name in prefer:
             ok, why = True, ""
             ident = [None]
-            if name == "rccl":  # every rank takes part in the broadcast even when rank 0 could not make an id
+            if name == "rccl":
+                # ncclCommInitRank blocks until every rank has called it: first make sure, collectively, that every
+                # rank can load librccl at all (a rank that cannot would leave the others waiting in the rendezvous)
+                try:
+                    rccl_unique_id()  # loads and binds the library; the id itself is discarded
+                    loadable = True
+                except Exception as e:  # noqa: BLE001
+                    loadable, why = False, str(e)
+                if not agree(loadable):
+                    if log and self.rank == 0:
+                        log("sequence: transport rccl unavailable (%s)" % (why or "a peer cannot load librccl"))
+                    continue
+                # every rank takes part in the broadcast even when rank 0 could not make an id
                 if self.rank == 0:
                     try:
                         ident = [rccl_unique_id()]

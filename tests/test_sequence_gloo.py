@@ -70,7 +70,10 @@ def _worker(rank, world, port, out_dir, partition, mode):
     seq.exchange_inputs(dist, mode)  # colour guides of the halo frames, once, before the level loop
     levels = list(range(len(sizes) - 1, -1, -1))
     received = sequence.run_schedule(seq, levels, FIRST, LAST, rank, world, 2, partition, dist, mode)
+    # what bench.py prints per rank: CRC-32 of every owned frame's level-0 disparity
+    crc = seq.result_crc()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), received=received,
+             crc_frames=np.array(sorted(crc), dtype=np.int64), crc_values=np.array([crc[t] for t in sorted(crc)], dtype=np.int64),
              **{"f%d_l%d" % (t, lv): seq.disp[t][lv].numpy() for t in seq.owned for lv in levels})
     dist.destroy_process_group()
 
@@ -99,9 +102,11 @@ def test_ranks_match_single_process(tmp_path, world, partition, mode):
     n, res, rig, sizes = _setup()
     seen = set()
     total_received = 0
+    crc = {}
     for rank in range(world):
         z = np.load(os.path.join(str(tmp_path), "rank%d.npz" % rank))
         total_received += int(z["received"])
+        crc.update({int(t): int(v) for t, v in zip(z["crc_frames"], z["crc_values"])})
         for t in sequence.owned_frames(FIRST, LAST, world, rank, partition):
             seen.add(t)
             for lv in levels:
@@ -109,6 +114,8 @@ def test_ranks_match_single_process(tmp_path, world, partition, mode):
                 same = (got == want) | (np.isnan(got) & np.isnan(want))
                 assert same.all(), (rank, t, lv, int((~same).sum()))
     assert seen == set(range(FIRST, LAST + 1))
+    # the per-frame CRCs the ranks would print (bench.py's result_crc) equal the single-process run's
+    assert crc == ref.result_crc()
     # exactly the planned halo traffic crossed ranks: one [D][h][w] f32 level per (transfer, level)
     per_transfer = sum(w * h for (w, h) in sizes) * n * 4
     assert total_received == len(sequence.plan(FIRST, LAST, world, 2, partition)) * per_transfer
