@@ -26,18 +26,38 @@ root = tempfile.mkdtemp(prefix="derp_cli_", dir="/tmp")
 t0 = time.time()
 synth.write_dataset(root, rig, list(range(frames)), sizes)
 print("dataset: %d frame(s) of %s written in %.1f s under %s" % (frames, cfg, time.time() - t0, root))
-for binary, threads in [(b, t) for b in binary.split(",") for t in threads.split(",")]:
-    out = os.path.join(root, "out_%s_%s" % (binary, threads))
+# CLI_EXTRA="--resident_frames=5;" runs every binary once per ';'-separated flag set (empty = the plain run) and
+# compares the level-0 PFMs of the runs byte for byte
+extras = os.environ.get("CLI_EXTRA", "").split(";") if os.environ.get("CLI_EXTRA") else [""]
+outs = []
+for binary, threads, extra in [(b, t, e) for b in binary.split(",") for t in threads.split(",") for e in extras]:
+    out = os.path.join(root, "out_%s_%s_%d" % (binary, threads, len(outs)))
+    outs.append(out)
     t0 = time.time()
     p = subprocess.run([os.path.join(ROOT, "facebook360_dep_amd", "bin", binary), "--input_root=" + root,
                         "--output_root=" + out, "--first=000000", "--last=%06d" % (frames - 1), "--resolution=%d" % res,
-                        "--threads=" + threads] + (["--partial_coverage"] if n <= 4 else []), capture_output=True, text=True)
+                        "--threads=" + threads] + (["--partial_coverage"] if n <= 4 else []) + extra.split(),
+                       capture_output=True, text=True)
     wall = time.time() - t0
-    print("%s --threads=%s rc=%d, wall %.2f s for %d frame(s) = %.1f Mpix/s from disk to disk" % (
-        binary, threads, p.returncode, wall, frames, frames * n * res * res / wall / 1e6))
+    print("%s --threads=%s %s rc=%d, wall %.2f s for %d frame(s) = %.1f Mpix/s from disk to disk" % (
+        binary, threads, extra, p.returncode, wall, frames, frames * n * res * res / wall / 1e6))
     for line in p.stderr.splitlines():
         if "-- I/O" in line or "-- TOTAL" in line or "-- rank" in line or "-- inputs" in line or "-- start-up" in line or \
                 re.search(r"\(level \d+\)$", line):
             print(line)
+        if "frame slot(s) in HBM" in line:
+            print(line)
     if p.returncode:
         print(p.stderr[-2000:])
+if len(outs) > 1:
+    import filecmp
+
+    base = os.path.join(outs[0], "disparity_levels", "level_0")
+    for other in outs[1:]:
+        same = total = 0
+        for cam in sorted(os.listdir(base)):
+            for f in sorted(os.listdir(os.path.join(base, cam))):
+                total += 1
+                same += filecmp.cmp(os.path.join(base, cam, f), os.path.join(other, "disparity_levels", "level_0", cam, f),
+                                    shallow=False)
+        print("%s vs %s: %d of %d level-0 files byte-identical" % (os.path.basename(other), os.path.basename(outs[0]), same, total))
