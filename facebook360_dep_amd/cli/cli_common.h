@@ -786,9 +786,143 @@ inline std::vector<uint8_t> load_mask(const fs::path& path, int& w, int& h) {
   return out;
 }
 // cv_util::loadImage<float>: PFM as is; PNG scaled to [0,1]
+// ---------------------------------------------------------------- OpenEXR (input)
+// What cv::imread reads back where a directory holds the .exr files --output_formats=exr wrote (they sort before the
+// .pfm of the same frame, so getFirstExtension-style lookups pick them): single-part scan-line files with exactly
+// one FLOAT channel, compression NONE / ZIPS / ZIP. Anything else is refused by name.
+struct ExrInfo {
+  int w = 0, h = 0, compression = 0;
+  size_t tableOffset = 0;
+};
+inline bool exr_header(const std::string& data, const fs::path& path, ExrInfo& info, bool fatal) {
+  auto bad = [&](const std::string& why) {
+    if (fatal) {
+      LOG_FATAL("unsupported OpenEXR file (" + why + "): " + path.string());
+    }
+    return false;
+  };
+  if (data.size() < 12 || memcmp(data.data(), "\x76\x2f\x31\x01", 4) != 0) {
+    return bad("bad magic");
+  }
+  uint32_t version;
+  memcpy(&version, data.data() + 4, 4);
+  if ((version & 0xff) != 2 || (version & 0x1a00)) {
+    return bad("tiled / multi-part / deep");
+  }
+  size_t pos = 8;
+  bool haveChannels = false, haveWindow = false;
+  while (pos < data.size() && data[pos] != 0) {
+    const size_t e = data.find('\0', pos);
+    const size_t e2 = e == std::string::npos ? e : data.find('\0', e + 1);
+    if (e2 == std::string::npos || e2 + 5 > data.size()) {
+      return bad("truncated header");
+    }
+    const std::string name = data.substr(pos, e - pos);
+    int32_t size;
+    memcpy(&size, data.data() + e2 + 1, 4);
+    const size_t val = e2 + 5;
+    if (size < 0 || val + (size_t)size > data.size()) {
+      return bad("truncated header");
+    }
+    if (name == "channels") {
+      const size_t ce = data.find('\0', val);
+      int32_t ptype = -1;
+      if (ce != std::string::npos && ce + 5 <= val + size) {
+        memcpy(&ptype, data.data() + ce + 1, 4);
+      }
+      // one channel = name\0 + 16 bytes, then the list's terminating \0
+      if (ptype != 2 || ce + 17 != val + (size_t)size - 1) {
+        return bad("needs exactly one FLOAT channel");
+      }
+      haveChannels = true;
+    } else if (name == "compression" && size == 1) {
+      info.compression = (unsigned char)data[val];
+    } else if (name == "dataWindow" && size == 16) {
+      int32_t b[4];
+      memcpy(b, data.data() + val, 16);
+      info.w = b[2] - b[0] + 1;
+      info.h = b[3] - b[1] + 1;
+      haveWindow = b[0] == 0 && b[1] == 0;
+    }
+    pos = val + size;
+  }
+  if (!haveChannels || !haveWindow || info.w <= 0 || info.h <= 0) {
+    return bad("missing channels / dataWindow");
+  }
+  if (info.compression != 0 && info.compression != 2 && info.compression != 3) {
+    return bad("compression other than NONE / ZIPS / ZIP");
+  }
+  info.tableOffset = pos + 1;
+  return true;
+}
+inline std::string read_file(const fs::path& path) {
+  std::ifstream f(path, std::ios::binary);
+  CHECK_MSG(f.good(), "failed to load image: " + path.string());
+  std::stringstream ss;
+  ss << f.rdbuf();
+  return ss.str();
+}
+inline bool exr_size(const fs::path& path, int& w, int& h) {
+  std::ifstream f(path, std::ios::binary);
+  std::string head(4096, '\0');
+  f.read(&head[0], (std::streamsize)head.size());
+  head.resize((size_t)f.gcount());
+  ExrInfo info;
+  if (!exr_header(head, path, info, false)) {
+    return false;
+  }
+  w = info.w;
+  h = info.h;
+  return true;
+}
+inline std::vector<float> read_exr_f32(const fs::path& path, int& w, int& h) {
+  const std::string data = read_file(path);
+  ExrInfo info;
+  exr_header(data, path, info, true);
+  w = info.w;
+  h = info.h;
+  const int lines = info.compression == 3 ? 16 : 1;
+  const int blocks = (h + lines - 1) / lines;
+  CHECK_MSG(info.tableOffset + (size_t)blocks * 8 <= data.size(), "truncated OpenEXR file: " + path.string());
+  std::vector<float> out((size_t)w * h);
+  std::vector<unsigned char> tmp;
+  for (int b = 0; b < blocks; ++b) {
+    uint64_t off;
+    memcpy(&off, data.data() + info.tableOffset + (size_t)b * 8, 8);
+    CHECK_MSG(off + 8 <= data.size(), "truncated OpenEXR file: " + path.string());
+    int32_t y, size;
+    memcpy(&y, data.data() + off, 4);
+    memcpy(&size, data.data() + off + 4, 4);
+    const int n = std::min(lines, h - y);
+    CHECK_MSG(y >= 0 && y < h && n > 0 && size >= 0 && off + 8 + (size_t)size <= data.size(), "corrupt OpenEXR chunk: " + path.string());
+    const size_t raw = (size_t)n * w * 4;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(data.data() + off + 8);
+    unsigned char* dst = reinterpret_cast<unsigned char*>(out.data() + (size_t)y * w);
+    if (info.compression == 0 || (size_t)size == raw) {
+      CHECK_MSG((size_t)size == raw, "corrupt OpenEXR chunk: " + path.string());
+      memcpy(dst, src, raw);
+      continue;
+    }
+    tmp.resize(raw);
+    uLongf got = (uLongf)raw;
+    CHECK_MSG(uncompress(tmp.data(), &got, src, (uLong)size) == Z_OK && got == raw, "OpenEXR inflate failed: " + path.string());
+    for (size_t i = 1; i < raw; ++i) {  // undo the predictor ...
+      tmp[i] = (unsigned char)(tmp[i - 1] + tmp[i] - 128);
+    }
+    const unsigned char *t1 = tmp.data(), *t2 = tmp.data() + (raw + 1) / 2;  // ... and the byte de-interleave
+    for (size_t i = 0; i < raw; ++i) {
+      dst[i] = (i & 1) ? *t2++ : *t1++;
+    }
+  }
+  return out;
+}
+
 inline std::vector<float> load_float(const fs::path& path, int& w, int& h) {
   if (path.extension() == ".pfm") {
     return read_pfm(path, w, h);
+  }
+  if (path.extension() == ".exr") {
+    return read_exr_f32(path, w, h);
   }
   const Png p = read_png(path);
   w = p.w;
@@ -801,9 +935,9 @@ inline std::vector<float> load_float(const fs::path& path, int& w, int& h) {
   return out;
 }
 inline bool image_size(const fs::path& path, int& w, int& h) {
-  return path.extension() == ".pfm" ? pfm_size(path, w, h) : png_size(path, w, h);
+  return path.extension() == ".pfm" ? pfm_size(path, w, h) : path.extension() == ".exr" ? exr_size(path, w, h) : png_size(path, w, h);
 }
-// ---------------------------------------------------------------- OpenEXR (output only)
+// ---------------------------------------------------------------- OpenEXR (output)
 // What cv::imwrite(".exr", CV_32FC1) leaves behind for --output_formats=exr (PyramidLevel.h:515-516,
 // CvUtil.cpp:30-37): a single-part scan-line OpenEXR 2 file with one 32-bit FLOAT channel "Y", ZIP compression
 // (blocks of 16 scan lines; OpenEXR's default, which OpenCV does not override), increasing-Y line order. Written

@@ -342,6 +342,17 @@ def test_output_format_exr(dataset, tmp_path):
     p = run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "x"), "--first=000000",
             "--last=000000", "--partial_coverage", "--resolution=96", "--output_formats=tiff", expect_ok=False)
     assert p.returncode != 0 and "Invalid output format" in p.stderr
+    # downstream binaries find the .exr first (it sorts before the .pfm of the same frame, ImageUtil.h:48-56's
+    # first-extension lookup) and must read it, as cv::imread does: same filtered level as from a pfm-only directory
+    plain = str(tmp_path / "p")
+    run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + plain, "--first=000000", "--last=000000",
+        "--partial_coverage", "--resolution=96")
+    rigf = os.path.join(dataset["root"], "rigs", "rig_calibrated.json")
+    for root_out in (out, plain):
+        run("TemporalBilateralFilter", "--input_root=" + dataset["root"], "--output_root=" + root_out, "--rig=" + rigf,
+            "--first=000000", "--last=000000", "--level=0")
+    name = os.path.join("disparity_time_filtered_levels", "level_0", ids[1], "000000.pfm")
+    assert open(os.path.join(out, name), "rb").read() == open(os.path.join(plain, name), "rb").read()
 
 
 def test_upsample_cli(dataset, tmp_path):
