@@ -27,8 +27,8 @@ for g in (1, 2):
 for short, r in row.items():
     wc = r.get("SQ_WAVE_CYCLES", 0) or 1
     print("%-18s %-4s" % (name, short), " ".join("%s=%.3g" % (c.replace("SQ_", ""), v) for c, v in sorted(r.items())))
-    print("%-18s %-4s shares of wave-cycles: VALU %.3f SCA %.3f LDS %.3f WAIT_ANY %.3f WAIT_INST %.3f | waves/SIMD avg %.2f" % (
+    print("%-18s %-4s shares of wave-cycles: VALU %.3f SCA %.3f LDS %.3f WAIT_ANY %.3f WAIT_INST %.3f" % (
         name, short, r.get("SQ_ACTIVE_INST_VALU", 0) / wc, r.get("SQ_ACTIVE_INST_SCA", 0) / wc, r.get("SQ_ACTIVE_INST_LDS", 0) / wc,
-        r.get("SQ_WAIT_ANY", 0) / wc, r.get("SQ_WAIT_INST_ANY", 0) / wc, wc / (r.get("SQ_BUSY_CYCLES", 1) or 1) / 4 * 8 / 8))
+        r.get("SQ_WAIT_ANY", 0) / wc, r.get("SQ_WAIT_INST_ANY", 0) / wc))
 PY
 done
