@@ -289,6 +289,9 @@ def main():
     # the counter numerators were collected on ONE version of the kernels: with any other, cycles and time would
     # come from different programs, so the counter-derived fields are withheld (tools/profile_round.sh re-collects)
     here = kernel_sources_sha256()
+    if prof and os.environ.get("DERP_LIB"):  # a developer's variant library (tools/variants.sh): not the profiled binary
+        stale = "DERP_LIB selects another library than the one the counters were collected on: counter-derived fields withheld"
+        prof = {}
     if prof and prof.get("kernel_sources_sha256") != here:
         stale = ("profiles/valu_roofline.json was collected on kernel sources %s..., this tree is %s...: counter-derived "
                  "fields withheld" % (str(prof.get("kernel_sources_sha256"))[:12], here[:12]))
