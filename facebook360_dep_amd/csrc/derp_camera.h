@@ -76,6 +76,7 @@ DERP_HD double undistort(const Cam& c, const double y) {
   return x0;
 }
 
+static constexpr int kAtanLutDoubles = 20;  // atan2_ypos_lut's table: 5 rows of {atanhi, atanlo, c, pad}
 #if defined(__HIP_DEVICE_COMPILE__)
 // IEEE fp64 division for operands whose quotient neither overflows nor underflows: the reciprocal-refinement
 // sequence the compiler emits for `/` (two Newton steps, quotient, one correction) without its exponent
@@ -134,16 +135,66 @@ __device__ __forceinline__ double atan2_ypos(double y, double x) {
   }
   return r;
 }
+
+// The same routine with the five-way choice of (atanhi, atanlo, c) read from a table in LDS by a per-lane index
+// instead of selected from scalar literals. With the literals in scalar registers (sk() above) the compiler can only
+// choose per lane by branching on the execution mask: 8 nested s_and_saveexec / s_cbranch diamonds — about a hundred
+// scalar instructions and a dozen v_readlane / v_writelane scalar-spill moves inside every projection. Here the
+// index is the number of breakpoints the lane's argument lies above (four compares feeding v_addc), the constants
+// arrive with two LDS reads, and c = 0 serves the first interval: fma(-0, ax, y) = y and fma(0, y, ax) = ax exactly.
+// Bit-identical to atan2_ypos for finite arguments (test_lean_atan2_against_libm runs both).
+// lut: kAtanLutRows rows of {atanhi, atanlo, c, pad}, 32 bytes each (atan_lut_fill).
+__device__ __forceinline__ void atan_lut_fill(double* lut) {
+  const int i = (int)threadIdx.x;
+  if (i < kAtanLutDoubles) {
+    const int row = i >> 2, col = i & 3;
+    const double hi = row == 1 ? 4.63647609000806093515e-01 : row == 2 ? 7.85398163397448278999e-01
+                    : row == 3 ? 9.82793723247329054082e-01 : row == 4 ? 1.57079632679489655800e+00 : 0.0;
+    const double lo = row == 1 ? 2.26987774529616870924e-17 : row == 2 ? 3.06161699786838301793e-17
+                    : row == 3 ? 1.39033110312309984516e-17 : row == 4 ? 6.12323399573676603587e-17 : 0.0;
+    const double c = row == 1 ? 0.5 : row == 2 ? 1.0 : row == 3 ? 1.5 : 0.0;
+    lut[i] = col == 0 ? hi : col == 1 ? lo : col == 2 ? c : 0.0;
+  }
+}
+__device__ __forceinline__ double atan2_ypos_lut(double y, double x, const double* lut) {
+  const double ax = fabs(x);
+  const int idx = (int)!(y < 0.4375 * ax) + (int)!(y < 0.6875 * ax) + (int)!(y < 1.1875 * ax) + (int)!(y < 2.4375 * ax);
+  const double* row = lut + idx * 4;
+  const double hi = row[0], lo = row[1], c = row[2];
+  double num = __builtin_fma(-c, ax, y), den = __builtin_fma(c, y, ax);
+  const bool top = idx == 4;
+  num = top ? -ax : num;
+  den = top ? y : den;
+  const double t = div_plain(num, den);
+  const double z = t * t, w = z * z;
+  double s1 = __builtin_fma(w, sk(1.62858201153657823623e-02), sk(4.97687799461593236017e-02));
+  s1 = __builtin_fma(w, s1, sk(6.66107313738753120669e-02));
+  s1 = __builtin_fma(w, s1, sk(9.09088713343650656196e-02));
+  s1 = __builtin_fma(w, s1, sk(1.42857142725034663711e-01));
+  s1 = __builtin_fma(w, s1, sk(3.33333333333329318027e-01));
+  s1 = z * s1;
+  double s2 = __builtin_fma(w, sk(-3.65315727442169155270e-02), sk(-5.83357013379057348645e-02));
+  s2 = __builtin_fma(w, s2, sk(-7.69187620504482999495e-02));
+  s2 = __builtin_fma(w, s2, sk(-1.11111104054623557880e-01));
+  s2 = __builtin_fma(w, s2, sk(-1.99999999998764832476e-01));
+  s2 = w * s2;
+  double r = hi - ((t * (s1 + s2) - lo) - t);
+  if (x < 0) {
+    r = sk(3.1415926535897931160E+00) - (r - sk(1.2246467991473531772E-16));
+  }
+  return r;
+}
 #endif
 
-// Camera.h:301-341. LEAN (device, cost kernels only): fp64 atan2 / division through the routines above.
-template <bool LEAN = false>
-DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p) {
+// Camera.h:301-341. LEAN (device, cost kernels only): fp64 atan2 / division through the routines above
+// (1 = interval constants from scalar literals, 2 = from the table `atanLut` in LDS).
+template <int LEAN = 0>
+DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = nullptr) {
   if (c.type == DERP_FTHETA) {
     const double xy = sqrt(p.x * p.x + p.y * p.y);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (LEAN) {
-      const double r = atan2_ypos(xy, -p.z);
+      const double r = LEAN == 2 ? atan2_ypos_lut(xy, -p.z, atanLut) : atan2_ypos(xy, -p.z);
       const double s = div_plain(distort(c, r), xy);
       return {s * p.x, s * p.y};
     }
@@ -227,9 +278,9 @@ DERP_HD bool outside_image_circle(const Cam& c, double px, double py, double prx
 
 // Camera.h:184-190 (+154-164, 121-128, 180-182). Returns false if the point is outside the
 // FOV cone or projects off the sensor; pix in units of (principal, focal, res).
-template <bool LEAN = false>
+template <int LEAN = 0>
 DERP_HD bool sees(const Cam& c, const D3& rig, double prx, double pry, double fx, double fy,
-                  double resx, double resy, D2& pix) {
+                  double resx, double resy, D2& pix, const double* atanLut = nullptr) {
   const D3 v = {rig.x - c.pos[0], rig.y - c.pos[1], rig.z - c.pos[2]};
   // backward().dot(v): also the camera-space z used below. forward().dot(v) is its exact negation
   // (negating every product and the sums commutes with round-to-nearest), so it is not recomputed.
@@ -252,7 +303,7 @@ DERP_HD bool sees(const Cam& c, const D3& rig, double prx, double pry, double fx
       sum3(c.R[0] * v.x, c.R[1] * v.y, c.R[2] * v.z),
       sum3(c.R[3] * v.x, c.R[4] * v.y, c.R[5] * v.z),
       back};
-  const D2 s = camera_to_sensor<LEAN>(c, cam);
+  const D2 s = camera_to_sensor<LEAN>(c, cam, atanLut);
   pix.x = fx * s.x + prx;
   pix.y = fy * s.y + pry;
   return !(0 > pix.x || pix.x >= resx || 0 > pix.y || pix.y >= resy);

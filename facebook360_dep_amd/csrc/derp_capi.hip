@@ -123,7 +123,7 @@ struct derp_ctx {
   int cur = -1;
   int DB = 0;  // dst batch that fits the table budget
   DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask, pairCount;
-  DevBuf projWarp, projColor, projBias, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
+  DevBuf projWarp, projColor, projBias, projWarpInv, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
   DevBuf rayDir, behind;  // per destination pixel: ray direction [3][D][n] f64, sources facing away [D][n] (k_pixel_rays)
   int warpCachedLevel = -1;
   bool randomRanThisLevel = false;  // cost / confidence hold random-proposal results for this level
@@ -139,6 +139,7 @@ struct derp_ctx {
   int spiralN = 0, spiralRadius = -1;
 
   bool profiling = false;
+  bool noMemo = false;  // DERP_NO_MEMO (developer switch), read once in derp_create
   std::vector<TimedSpan> spans;
   double accMs[ST_COUNT][kMaxLevels];
   int accLaunch[ST_COUNT][kMaxLevels];
@@ -493,7 +494,7 @@ int upsample_masked_dev(derp_ctx* c, const float* in, const uint8_t* mask, int s
 
 size_t table_bytes_per_dst(const derp_ctx* c, int W, int H) {
   const size_t wp = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW), cp = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC);
-  return (size_t)(c->S - 1) * (wp * sizeof(float2) + 2 * cp * sizeof(ushort4));
+  return (size_t)(c->S - 1) * (wp * sizeof(float2) + 2 * cp * sizeof(ushort4) + (size_t)W * H * sizeof(float2));
 }
 
 int compute_fov_and_masks(derp_ctx* c, int level) {
@@ -527,31 +528,21 @@ int build_warp(derp_ctx* c, int dst0, int nd) {
   hipLaunchKernelGGL(k_pixel_rays, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->rayDir.as<double>(),
                      c->behind.as<unsigned>());
   KCHECK(c);
+  // ... and the inverse warps reprojectColors reads (projWarpInv, PyramidLevel.h:46-51)
+  hipLaunchKernelGGL(k_proj_warp_inv, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->projWarpInv.as<float2>());
+  KCHECK(c);
   return 0;
 }
 
 int build_color_tables(derp_ctx* c, int dst0, int nd) {
   const int L = c->cur;
   LevelView V = make_view(c, ST_REPROJECT, dst0, nd);
-  {
-    Span sp(c, ST_REPROJECT, L);
-    hipLaunchKernelGGL(k_reproject, grid2d(V.W + 2 * kPadC, V.H + 2 * kPadC, nd, kBlk2d), kBlk2d, 0, c->stream, V,
-                       c->projColor.as<ushort4>());
-    KCHECK(c);
-  }
-  {
-    Span sp(c, ST_PROJ_BIAS, L);
-    const size_t plane = (size_t)(V.W + 2 * kPadC) * (V.H + 2 * kPadC);
-    const int planes = nd * (c->S - 1);
-    // grid.z is limited to 65535
-    for (int p0 = 0; p0 < planes; p0 += 32768) {
-      const int np = std::min(32768, planes - p0);
-      hipLaunchKernelGGL(k_blur3_u16, blur_grid(V.W + 2 * kPadC, V.H + 2 * kPadC, np), kBlurBlk, 0, c->stream,
-                         c->projColor.as<ushort4>() + (size_t)p0 * plane, kPadC,
-                         c->projBias.as<ushort4>() + (size_t)p0 * plane, kPadC, V.W, V.H, plane, plane);
-      KCHECK(c);
-    }
-  }
+  // colours and their 3x3 biases in one pass (the bias stage's time is inside ST_REPROJECT now)
+  Span sp(c, ST_REPROJECT, L);
+  hipLaunchKernelGGL(k_reproject_bias, dim3((V.W + kRbTile - 1) / kRbTile, (V.H + kRbTile - 1) / kRbTile, nd * (c->S - 1)),
+                     dim3(256), 0, c->stream, V, c->projWarpInv.as<float2>(), c->projColor.as<ushort4>(),
+                     c->projBias.as<ushort4>());
+  KCHECK(c);
   return 0;
 }
 
@@ -628,7 +619,7 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
     hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->changed.as<uint8_t>(),
                        c->dispRes.as<float>(), c->costRes.as<float>(), tilesX,
-                       (int)(it == 1 && c->randomRanThisLevel && !getenv("DERP_NO_MEMO")));
+                       (int)(it == 1 && c->randomRanThisLevel && !c->noMemo));
     KCHECK(c);
     hipLaunchKernelGGL(k_ping_pong_commit, dim3(flat_grid(n * nd)), dim3(256), 0, c->stream,
                        c->disparity.as<float>() + (size_t)dst0 * n, c->cost.as<float>() + (size_t)dst0 * n,
@@ -675,7 +666,8 @@ int bilateral_radius(int level) {  // Derp.cpp:876-878
 }
 
 size_t bilateral_lds_bytes(int radius) {
-  const size_t t = (size_t)(16 + 2 * radius) * (16 + 2 * radius);
+  // rows of the tile are padded to a multiple of 16 texels (k_joint_bilateral: bank-conflict-free float4 reads)
+  const size_t t = (size_t)((16 + 2 * radius + 15) & ~15) * (16 + 2 * radius);
   return t * 4 * sizeof(float) + ((t + 3) & ~(size_t)3);
 }
 
@@ -795,12 +787,13 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   {
     const size_t wpAll = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW) * (c->S - 1) * c->D * sizeof(float2);
     const size_t cpAll = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC) * (c->S - 1) * c->D * sizeof(ushort4);
+    const size_t ipAll = (size_t)W * H * (c->S - 1) * c->D * sizeof(float2);
     const bool resident = c->projWarp.bytes >= wpAll && c->projColor.bytes >= cpAll && c->projBias.bytes >= cpAll &&
-        !getenv("DERP_TABLE_BUDGET_GB");
+        c->projWarpInv.bytes >= ipAll && !getenv("DERP_TABLE_BUDGET_GB");
     if (!resident) {
       size_t freeB = 0, totalB = 0;
       HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
-      size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes;
+      size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes + c->projWarpInv.bytes;
       if (const char* e = getenv("DERP_TABLE_BUDGET_GB")) {
         budget = std::min<size_t>(budget, (size_t)(atof(e) * (1ull << 30)));
       } else {
@@ -820,6 +813,7 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   ALLOC(c, c->projWarp, (size_t)DB * (c->S - 1) * wp * sizeof(float2));
   ALLOC(c, c->projColor, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
   ALLOC(c, c->projBias, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
+  ALLOC(c, c->projWarpInv, (size_t)DB * (c->S - 1) * n * sizeof(float2));
   c->tablesValid = false;
   c->randomRanThisLevel = false;
   if (buildAllTables) {
@@ -1006,6 +1000,7 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
   if (const char* e = getenv("DERP_XCD_ROTATE")) {
     c->xcdRotate = atoi(e);
   }
+  c->noMemo = getenv("DERP_NO_MEMO") != nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking) != hipSuccess) {
     return bail("hipStreamCreate failed");
@@ -1071,7 +1066,7 @@ void derp_destroy(derp_ctx* c) {
   c->devMask.release();
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
                     &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
-                    &c->projWarp, &c->projColor, &c->projBias, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
+                    &c->projWarp, &c->projColor, &c->projBias, &c->projWarpInv, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
   }

@@ -50,6 +50,17 @@ namespace derp {
 #ifndef DERP_LEAN_PROJ
 #define DERP_LEAN_PROJ 1
 #endif
+// the short atan2's per-interval constants from a table in LDS (1) or from scalar literals chosen by branching (0)
+#ifndef DERP_ATAN_LUT
+#define DERP_ATAN_LUT 1
+#endif
+// computeSSD's 4x4-block arithmetic in plain fp32 (1) or packed fp32 (0), per kernel family
+#ifndef DERP_RANDOM_SSD_SCALAR
+#define DERP_RANDOM_SSD_SCALAR 1
+#endif
+#ifndef DERP_COST_SSD_SCALAR
+#define DERP_COST_SSD_SCALAR 0
+#endif
 static constexpr int kPadW = 1;   // ring of projWarp
 static constexpr int kPadC = 2;   // ring of projColor / projBias
 static constexpr int kMaxSrc = 32;
@@ -186,6 +197,7 @@ struct PixCtx {
 struct LdsPairs {
   SsdPair* base;
   int stride;
+  const double* atanLut;  // atan_lut_fill's table, or null: select the constants from scalar literals
   __device__ __forceinline__ SsdPair get(int i) const {
     return base[i * stride];
   }
@@ -228,6 +240,7 @@ __device__ __forceinline__ void ssd_issue(const LevelView& V, const ushort4* __r
 
 // computeSSD (DerpUtil.cpp:126-162) for one source whose projected tables are `col` / `bias`; `T` holds the
 // texels ssd_issue requested for (xDstSrc, yDstSrc).
+template <bool SCALAR>
 __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
                                              const SsdTexels& T, float xDstSrc, float yDstSrc) {
 #ifdef DERP_ABLATE_NO_SSD
@@ -270,7 +283,57 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
   // in the reference's dx-outer / dy-inner order afterwards.
   // xwp = (xw[0], xw[2]), xwm = xw[1]; yw[iy] per offset row.
   float first = 0.f, second = 0.f;
-  auto block = [&](v2f xwp, float xwm, const float (&yw)[3]) {
+  // The same block in plain (unpacked) fp32 — identical operations in identical order per channel. It needs no
+  // register pairs: random proposals then fit 166 VGPRs = three waves per SIMD without a spill (192 / two waves
+  // packed), which is what a kernel that waits on cache misses wants; ping-pong, which is bound by VALU issue, is
+  // faster packed (half the instructions for the same pipe time: a packed op holds both halves of the SIMD for four
+  // cycles, v_add / v_sub / v_mul_f32 hold one half each — tools/valu_ubench.hip). A/B: profiles/r04_kernel_variants.txt
+  auto block_scalar = [&](v2f xwp, float xwm, const float (&yw)[3]) {
+    struct RowS {
+      float c[3][4];  // [channel][texel column]
+    };
+    auto unpack = [](const u4a8& a, const u4a8& b, RowS& t) {
+      t.c[0][0] = (float)(a.x & 0xffff); t.c[1][0] = (float)(a.x >> 16); t.c[2][0] = (float)(a.y & 0xffff);
+      t.c[0][1] = (float)(a.z & 0xffff); t.c[1][1] = (float)(a.z >> 16); t.c[2][1] = (float)(a.w & 0xffff);
+      t.c[0][2] = (float)(b.x & 0xffff); t.c[1][2] = (float)(b.x >> 16); t.c[2][2] = (float)(b.y & 0xffff);
+      t.c[0][3] = (float)(b.z & 0xffff); t.c[1][3] = (float)(b.z >> 16); t.c[2][3] = (float)(b.w & 0xffff);
+    };
+    const float xw3[3] = {xwp.x, xwm, xwp.y};
+    float d0s[3][3], d1s[3][3];  // [ix][iy]
+    RowS lo, hi;
+    unpack(raw[0][0], raw[0][1], lo);
+#pragma unroll
+    for (int iy = 0; iy < 3; ++iy) {
+      unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+      const float omy = 1 - yw[iy];
+#pragma unroll
+      for (int ix = 0; ix < 3; ++ix) {
+        const float omx = 1 - xw3[ix];
+        const float w00 = omx * omy, w01 = xw3[ix] * omy, w10 = omx * yw[iy], w11 = xw3[ix] * yw[iy];
+        float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = w00 * lo.c[c][ix] + w01 * lo.c[c][ix + 1] + w10 * hi.c[c][ix] + w11 * hi.c[c][ix + 1];
+          const float db = px.patch(ix * 3 + iy, c) - __builtin_truncf(v);
+          const float dn = db - bias[c];
+          d0 = c == 0 ? db * db : d0 + db * db;
+          d1 = c == 0 ? dn * dn : d1 + dn * dn;
+        }
+        d0s[ix][iy] = d0;
+        d1s[ix][iy] = d1;
+      }
+      lo = hi;
+    }
+#pragma unroll
+    for (int ix = 0; ix < 3; ++ix) {
+#pragma unroll
+      for (int iy = 0; iy < 3; ++iy) {
+        first += d0s[ix][iy];
+        second += d1s[ix][iy];
+      }
+    }
+  };
+  auto block_packed = [&](v2f xwp, float xwm, const float (&yw)[3]) {
     struct RowF {
       v2f bg[4];   // (B, G) of texel columns 0..3
       v2f rA, rB;  // R of columns (0, 2) and (1, 3)
@@ -374,7 +437,11 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
   }
   if (regular) {
-    block((v2f){xw[0], xw[2]}, xw[1], yw);
+    if constexpr (SCALAR) {
+      block_scalar((v2f){xw[0], xw[2]}, xw[1], yw);
+    } else {
+      block_packed((v2f){xw[0], xw[2]}, xw[1], yw);
+    }
   } else {
     // float rounding of x + dx crossed a .5 boundary: taps no longer form a 4x4 block
     for (int ix = 0; ix < 3; ++ix) {
@@ -407,11 +474,12 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
   const float scale = 1.0f / (65535.0f * 65535.0f);
   return {first * scale, second * scale};
 }
+template <bool SCALAR>
 __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
                                                const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc) {
   SsdTexels T;
   ssd_issue(V, col, bia, xDstSrc, yDstSrc, T);
-  return ssd_arith(V, px, col, T, xDstSrc, yDstSrc);
+  return ssd_arith<SCALAR>(V, px, col, T, xDstSrc, yDstSrc);
 }
 
 // Sources that cannot see this wave's pixels at ANY candidate depth: the pixel's ray O + t D, pushed through a
@@ -463,6 +531,8 @@ __device__ __forceinline__ unsigned behind_sources(const LevelView& V, int d, si
 // The fp64 projection state and the 4x4 texel block are never live together.
 // `cull` (wave-uniform, from behind_sources): slots of sources that no lane of the wave can see at any depth >=
 // kCullMinDepth; they are skipped without their cone test. 0 = test every source.
+// SCALAR: computeSSD's block arithmetic in plain instead of packed fp32 (ssd_arith).
+template <bool SCALAR = false>
 __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int own, const PixCtx& px, float disparity,
                                                LdsPairs& pairs, unsigned& nPair, unsigned cull = 0) {
   const double depth = (double)(1.0f / disparity);
@@ -508,8 +578,8 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       pn.y = 0.5 + 0.45 * (double)(fy - floorf(fy) - 0.5f);
       const bool vis = (s & 1) != 0;
 #else
-      const bool vis = sees<DERP_LEAN_PROJ != 0>(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1],
-                                                 1.0, 1.0, pn);
+      const bool vis = sees<(DERP_LEAN_PROJ != 0) * (DERP_ATAN_LUT ? 2 : 1)>(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1],
+                                                 1.0, 1.0, pn, pairs.atanLut);
 #endif
       if (__ballot(pend) != 0ull) {
         consume();
@@ -549,7 +619,7 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       const int t = __builtin_ctz(wm);
       if ((mask >> t) & 1) {
         const SsdPair e = pairs.get(t);
-        const SsdPair ssd = compute_ssd(V, px, colBase + (size_t)t * cPlane, biaBase + (size_t)t * cPlane, e.first, e.second);
+        const SsdPair ssd = compute_ssd<SCALAR>(V, px, colBase + (size_t)t * cPlane, biaBase + (size_t)t * cPlane, e.first, e.second);
         pairs.set(cnt, ssd);
         ++cnt;
       }
@@ -632,8 +702,15 @@ __global__ void k_debug_atan2_ypos(const double* __restrict__ y, const double* _
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t step = (size_t)gridDim.x * blockDim.x;
 #if defined(__HIP_DEVICE_COMPILE__)  // the routine exists in the device pass only
+  // what the cost kernels evaluate (the table variant when DERP_ATAN_LUT), checked against the literal variant on
+  // the spot: a bitwise disagreement between the two is reported as NaN, which no caller's comparison survives
+  __shared__ double atanLut[kAtanLutDoubles];
+  atan_lut_fill(atanLut);
+  __syncthreads();
   for (; i < n; i += step) {
-    out[i] = atan2_ypos(y[i], x[i]);
+    const double a = atan2_ypos(y[i], x[i]);
+    const double b = atan2_ypos_lut(y[i], x[i], atanLut);
+    out[i] = (__double_as_longlong(a) == __double_as_longlong(b)) ? (DERP_ATAN_LUT ? b : a) : __builtin_nan("");
   }
 #endif
 }
@@ -850,97 +927,181 @@ __device__ __forceinline__ int cv_round(float v) {
   return (int)rintf(v);
 }
 
-// reprojectColors (Derp.cpp:978-1003): projColor(d, s) = cv::remap(srcColor[s], projWarpInv(d, s),
-// INTER_CUBIC, BORDER_CONSTANT 0) (DerpUtil.cpp:199-205). projWarpInv is not materialised: the
-// dst-pixel ray is computed once per thread and pushed through every src (ImageUtil.cpp:142-167),
-// the float coordinate goes straight into the remap arithmetic (1/32-px fixed point, 4x4 taps,
-// float weights, saturate_cast<ushort> = round-half-even).
-__global__ void k_reproject(LevelView V, ushort4* __restrict__ projColor) {
-  const int dl = blockIdx.z;
-  const int d = V.dst0 + dl;
-  const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
-  const int OW = V.W + 2 * kPadC, OH = V.H + 2 * kPadC;
-  if (ox >= OW || oy >= OH) {
-    return;
+// cv::remap(src, map, INTER_CUBIC, BORDER_CONSTANT 0) at ONE map coordinate (mx, my) of a CV_16UC3 image
+// (DerpUtil.cpp:199-205): 1/32-px fixed point, 4x4 taps, float weights, saturate_cast<ushort> = round-half-even.
+__device__ __forceinline__ ushort4 remap_cubic_u16(const ushort4* __restrict__ img, int W, int H, float mx, float my) {
+  const int fsx = cv_round(mx * 32.0f), fsy = cv_round(my * 32.0f);
+  const int fx = fsx & 31, fy = fsy & 31;
+  const int sx = min(max(fsx >> 5, -32768), 32767) - 1, sy = min(max(fsy >> 5, -32768), 32767) - 1;
+  float cx[4], cy[4];
+  cubic_coeffs((float)fx * (1.f / 32), cx);
+  cubic_coeffs((float)fy * (1.f / 32), cy);
+  float sum[3];
+  if ((unsigned)sx < (unsigned)max(W - 3, 0) && (unsigned)sy < (unsigned)max(H - 3, 0)) {
+    float rowsum[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // the four texels of a tap row as two 16-byte loads (8-byte aligned)
+      const u4a8* r = reinterpret_cast<const u4a8*>(img + (size_t)(sy + i) * W + sx);
+      const u4a8 a = r[0], b = r[1];
+      const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
+      rowsum[i][0] = (float)(a.x & 0xffff) * w0 + (float)(a.z & 0xffff) * w1 + (float)(b.x & 0xffff) * w2 + (float)(b.z & 0xffff) * w3;
+      rowsum[i][1] = (float)(a.x >> 16) * w0 + (float)(a.z >> 16) * w1 + (float)(b.x >> 16) * w2 + (float)(b.z >> 16) * w3;
+      rowsum[i][2] = (float)(a.y & 0xffff) * w0 + (float)(a.w & 0xffff) * w1 + (float)(b.y & 0xffff) * w2 + (float)(b.w & 0xffff) * w3;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float acc = rowsum[0][c];
+      acc += rowsum[1][c];
+      acc += rowsum[2][c];
+      acc += rowsum[3][c];
+      sum[c] = acc;
+    }
+  } else if (sx >= W || sx + 4 <= 0 || sy >= H || sy + 4 <= 0) {
+    sum[0] = sum[1] = sum[2] = 0.f;
+  } else {
+    sum[0] = sum[1] = sum[2] = 0.f;
+    for (int i = 0; i < 4; ++i) {
+      const int yy = sy + i;
+      if ((unsigned)yy >= (unsigned)H) {
+        continue;
+      }
+      for (int j = 0; j < 4; ++j) {
+        const int xx = sx + j;
+        if ((unsigned)xx >= (unsigned)W) {
+          continue;
+        }
+        const ushort4 q = img[(size_t)yy * W + xx];
+        const float w = cy[i] * cx[j];
+        sum[0] += ((float)q.x - 0.f) * w;
+        sum[1] += ((float)q.y - 0.f) * w;
+        sum[2] += ((float)q.z - 0.f) * w;
+      }
+    }
   }
-  const int x = min(max(ox - kPadC, 0), V.W - 1), y = min(max(oy - kPadC, 0), V.H - 1);
-  const Cam& cd = V.camsDst[d];
-  const int own = V.dst2src[d];
+  const int r0 = min(max(cv_round(sum[0]), 0), 65535), r1 = min(max(cv_round(sum[1]), 0), 65535),
+            r2 = min(max(cv_round(sum[2]), 0), 65535);
+  return make_ushort4((unsigned short)r0, (unsigned short)r1, (unsigned short)r2, 0);
+}
+
+// The rig-space point a dst pixel's ray reaches at kNearInfinity (computeWarpDstToSrc, ImageUtil.cpp:142-167);
+// false outside the image circle.
+__device__ __forceinline__ bool dst_far_point(const LevelView& V, const Cam& cd, int x, int y, D3& rig) {
   const double W = V.W, H = V.H;
   const double dprx = cd.principal[0] * W, dpry = cd.principal[1] * H, dfx = cd.focal[0] * W, dfy = cd.focal[1] * H;
   const double px = x + 0.5, py = y + 0.5;
-  const bool outside = outside_image_circle(cd, px, py, dprx, dpry, dfx, dfy);
-  D3 rig = {0, 0, 0};
-  if (!outside) {
-    const D3 dir = rig_direction(cd, px, py, dprx, dpry, dfx, dfy);
-    rig = {cd.pos[0] + dir.x * 1e4, cd.pos[1] + dir.y * 1e4, cd.pos[2] + dir.z * 1e4};
+  if (outside_image_circle(cd, px, py, dprx, dpry, dfx, dfy)) {
+    return false;
   }
-  const size_t plane = (size_t)OW * OH;
+  const D3 dir = rig_direction(cd, px, py, dprx, dpry, dfx, dfy);
+  rig = {cd.pos[0] + dir.x * 1e4, cd.pos[1] + dir.y * 1e4, cd.pos[2] + dir.z * 1e4};
+  return true;
+}
+// projWarpInv(d, s)(x, y): where that point lands in src s, as cv::remap's map coordinate; NaN when it is not seen
+__device__ __forceinline__ float2 warp_inv_of(const LevelView& V, const Cam& cs, bool inside, const D3& rig) {
+  const double W = V.W, H = V.H;
+  D2 p;
+  if (inside && sees(cs, rig, cs.principal[0] * W, cs.principal[1] * H, cs.focal[0] * W, cs.focal[1] * H, W, H, p)) {
+    return make_float2((float)(p.x - (double)0.5f), (float)(p.y - (double)0.5f));
+  }
+  const float nan = __builtin_nanf("");
+  return make_float2(nan, nan);
+}
+
+// projWarpInv (PyramidLevel.h:46-51, the reference's second table) for the destinations of a batch, on the
+// UNPADDED dst grid: [D][S-1][H][W] float2. Rig and level size only, like projWarp: built with it (precomputeProjections,
+// Derp.cpp:955-976) and kept for as long as it is — every further frame of a sequence that runs this level skips
+// these fp64 projections (15 sources x Newton undistort / atan2 per pixel), which were the whole cost of
+// reprojectColors. The dst-pixel ray is computed once per thread and pushed through every src.
+__global__ void k_proj_warp_inv(LevelView V, float2* __restrict__ warpInv) {
+  const int dl = blockIdx.z;
+  const int d = V.dst0 + dl;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= V.W || y >= V.H) {
+    return;
+  }
+  const int own = V.dst2src[d];
+  D3 rig = {0, 0, 0};
+  const bool inside = dst_far_point(V, V.camsDst[d], x, y, rig);
   const size_t n = (size_t)V.W * V.H;
   for (int s = 0; s < V.S; ++s) {
-    if (s == own) {
-      continue;
+    if (s != own) {
+      warpInv[((size_t)dl * (V.S - 1) + slot(s, own)) * n + (size_t)y * V.W + x] = warp_inv_of(V, V.camsSrc[s], inside, rig);
     }
-    ushort4 outv = make_ushort4(0, 0, 0, 0);  // NaN map -> (-32768,-32768) -> constant border 0
-    D2 p;
-    const Cam& cs = V.camsSrc[s];
-    if (!outside &&
-        sees(cs, rig, cs.principal[0] * W, cs.principal[1] * H, cs.focal[0] * W, cs.focal[1] * H, W, H, p)) {
-      const float mx = (float)(p.x - (double)0.5f), my = (float)(p.y - (double)0.5f);
-      const int fsx = cv_round(mx * 32.0f), fsy = cv_round(my * 32.0f);
-      const int fx = fsx & 31, fy = fsy & 31;
-      const int sx = min(max(fsx >> 5, -32768), 32767) - 1, sy = min(max(fsy >> 5, -32768), 32767) - 1;
-      float cx[4], cy[4];
-      cubic_coeffs((float)fx * (1.f / 32), cx);
-      cubic_coeffs((float)fy * (1.f / 32), cy);
-      const ushort4* img = V.srcColor + (size_t)s * n;
-      float sum[3];
-      if ((unsigned)sx < (unsigned)max(V.W - 3, 0) && (unsigned)sy < (unsigned)max(V.H - 3, 0)) {
-        float rowsum[4][3];
+  }
+}
+
+// reprojectColors (Derp.cpp:978-1003) + the colour bias (DerpUtil.cpp:208-210) in one pass:
+//   projColor(d, s) = cv::remap(srcColor[s], projWarpInv(d, s), INTER_CUBIC, BORDER_CONSTANT 0)
+//   projBias(d, s)  = cv::blur 3x3 of projColor(d, s) on CV_16UC3, BORDER_REFLECT_101: exact integer sum, round(s / 9)
+// A block owns a 32 x 32 tile of dst pixels of ONE (dst, src) table (blockIdx.z). It remaps the tile and its
+// 1-pixel halo (34 x 34 positions, +13 % — the remap, 16 taps and ~250 VALU instructions per position, is the
+// expensive part; halo positions beyond the image are their BORDER_REFLECT_101 mirror pixels) into LDS, then every
+// thread writes four pixels' colours and their 3x3 boxes over the LDS tile — the separate blur pass read back from
+// HBM what the remap had just written (19.7 GB per level-0 launch, 68 % of its wave-cycles waiting). Both tables
+// carry a 2-texel replicated ring: edge pixels write their ring texels too.
+constexpr int kRbTile = 32, kRbPitch = kRbTile + 2, kRbCells = kRbPitch * kRbPitch;
+__global__ void __launch_bounds__(256)
+    k_reproject_bias(LevelView V, const float2* __restrict__ warpInv, ushort4* __restrict__ projColor,
+                     ushort4* __restrict__ projBias) {
+  __shared__ ushort4 tile[kRbCells];
+  const int tab = blockIdx.z;  // dl * (S - 1) + slot
+  const int dl = tab / (V.S - 1), sl = tab - dl * (V.S - 1);
+  const int own = V.dst2src[V.dst0 + dl];
+  const int s = sl < own ? sl : sl + 1;
+  const int x0 = blockIdx.x * kRbTile, y0 = blockIdx.y * kRbTile;
+  const int OW = V.W + 2 * kPadC, OH = V.H + 2 * kPadC;
+  const size_t plane = (size_t)OW * OH, n = (size_t)V.W * V.H;
+  const ushort4* img = V.srcColor + (size_t)s * n;
+  const float2* map = warpInv + (size_t)tab * n;
+  for (int k = threadIdx.x; k < kRbCells; k += 256) {
+    const int ty = k / kRbPitch, tx = k - ty * kRbPitch;
+    const int qx = x0 - 1 + tx, qy = y0 - 1 + ty;
+    if (qx >= -1 && qx <= V.W && qy >= -1 && qy <= V.H) {
+      const float2 m = map[(size_t)reflect101(qy, V.H) * V.W + reflect101(qx, V.W)];
+      // NaN map -> (-32768, -32768) in cv::remap's fixed point -> every tap outside -> constant border 0
+      tile[k] = (m.x != m.x) ? make_ushort4(0, 0, 0, 0) : remap_cubic_u16(img, V.W, V.H, m.x, m.y);
+    }
+  }
+  __syncthreads();
+  ushort4* pc = projColor + (size_t)tab * plane;
+  ushort4* pb = projBias + (size_t)tab * plane;
+  const int lx = threadIdx.x & 31;
+  const int x = x0 + lx;
+  if (x >= V.W) {
+    return;
+  }
+  const int oxa = x == 0 ? 0 : x + kPadC, oxb = x == V.W - 1 ? OW - 1 : x + kPadC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const ushort4* r = img + (size_t)(sy + i) * V.W + sx;
-          const ushort4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
-          const float w0 = cy[i] * cx[0], w1 = cy[i] * cx[1], w2 = cy[i] * cx[2], w3 = cy[i] * cx[3];
-          rowsum[i][0] = q0.x * w0 + q1.x * w1 + q2.x * w2 + q3.x * w3;
-          rowsum[i][1] = q0.y * w0 + q1.y * w1 + q2.y * w2 + q3.y * w3;
-          rowsum[i][2] = q0.z * w0 + q1.z * w1 + q2.z * w2 + q3.z * w3;
-        }
+  for (int j = 0; j < kRbTile / 8; ++j) {
+    const int ly = (int)(threadIdx.x >> 5) + 8 * j;
+    const int y = y0 + ly;
+    if (y >= V.H) {
+      break;
+    }
+    const ushort4* t = &tile[(ly + 1) * kRbPitch + lx + 1];
+    unsigned s0 = 0, s1 = 0, s2 = 0;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float acc = rowsum[0][c];
-          acc += rowsum[1][c];
-          acc += rowsum[2][c];
-          acc += rowsum[3][c];
-          sum[c] = acc;
-        }
-      } else if (sx >= V.W || sx + 4 <= 0 || sy >= V.H || sy + 4 <= 0) {
-        sum[0] = sum[1] = sum[2] = 0.f;
-      } else {
-        sum[0] = sum[1] = sum[2] = 0.f;
-        for (int i = 0; i < 4; ++i) {
-          const int yy = sy + i;
-          if ((unsigned)yy >= (unsigned)V.H) {
-            continue;
-          }
-          for (int j = 0; j < 4; ++j) {
-            const int xx = sx + j;
-            if ((unsigned)xx >= (unsigned)V.W) {
-              continue;
-            }
-            const ushort4 q = img[(size_t)yy * V.W + xx];
-            const float w = cy[i] * cx[j];
-            sum[0] += ((float)q.x - 0.f) * w;
-            sum[1] += ((float)q.y - 0.f) * w;
-            sum[2] += ((float)q.z - 0.f) * w;
-          }
-        }
+    for (int v = -1; v <= 1; ++v) {
+#pragma unroll
+      for (int u = -1; u <= 1; ++u) {
+        const ushort4 q = t[v * kRbPitch + u];
+        s0 += q.x;
+        s1 += q.y;
+        s2 += q.z;
       }
-      const int r0 = min(max(cv_round(sum[0]), 0), 65535), r1 = min(max(cv_round(sum[1]), 0), 65535),
-                r2 = min(max(cv_round(sum[2]), 0), 65535);
-      outv = make_ushort4((unsigned short)r0, (unsigned short)r1, (unsigned short)r2, 0);
     }
-    projColor[((size_t)dl * (V.S - 1) + slot(s, own)) * plane + (size_t)oy * OW + ox] = outv;
+    const ushort4 col = t[0];
+    const ushort4 bia = make_ushort4((unsigned short)((s0 + 4) / 9), (unsigned short)((s1 + 4) / 9),
+                                     (unsigned short)((s2 + 4) / 9), 0);
+    // padded coordinates this pixel writes: its own texel plus the ring texels that replicate it
+    const int oya = y == 0 ? 0 : y + kPadC, oyb = y == V.H - 1 ? OH - 1 : y + kPadC;
+    for (int oy = oya; oy <= oyb; ++oy) {
+      for (int ox = oxa; ox <= oxb; ++ox) {
+        pc[(size_t)oy * OW + ox] = col;
+        pb[(size_t)oy * OW + ox] = bia;
+      }
+    }
   }
 }
 
@@ -965,7 +1126,14 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int lane = threadIdx.x & 63;
   const int sx = (int)(blockIdx.x % (unsigned)tilesX), sy = (int)(blockIdx.x / (unsigned)tilesX);
   const int x = 1 + sx * 8 + (lane & 7), y = 1 + sy * 8 + (lane >> 3);
-  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+#if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
+  __shared__ double atanLut[kAtanLutDoubles];
+  atan_lut_fill(atanLut);
+  __syncthreads();
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
+#else
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
+#endif
   unsigned nCost = 0, nPair = 0;
   if (x <= iw && y <= ih) {
     const int own = V.dst2src[d];
@@ -978,7 +1146,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     if (fov && fg && closer) {
       PixCtx px;
       load_pixctx(V, d, own, x, y, px);
-      r = compute_cost(V, dl, own, px, disparity, pairs, nPair);
+      r = compute_cost<DERP_COST_SSD_SCALAR != 0>(V, dl, own, px, disparity, pairs, nPair);
       ++nCost;
     }
     const size_t o = ((size_t)dl * kNumDepths + i) * n + idx;
@@ -1107,7 +1275,14 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
   const int d = V.dst0 + dl;
   int x, y;
   tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0), tilesX, x, y);
-  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+#if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
+  __shared__ double atanLut[kAtanLutDoubles];
+  atan_lut_fill(atanLut);
+  __syncthreads();
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
+#else
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
+#endif
   unsigned nCost = 0, nPair = 0;
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
     const int own = V.dst2src[d];
@@ -1122,7 +1297,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
         const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float currDisp = disp[idx];
         unsigned before = nPair;
-        float2 cur = compute_cost(V, dl, own, px, currDisp, pairs, nPair, cull);
+        float2 cur = compute_cost<DERP_RANDOM_SSD_SCALAR != 0>(V, dl, own, px, currDisp, pairs, nPair, cull);
         ++nCost;
         unsigned currPairs = nPair - before;
         float currCost = cur.x, currConf = cur.y;
@@ -1135,7 +1310,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
           const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
           const float propDisp = minstd_uniform(state, lo, hi);
           before = nPair;
-          const float2 pr = compute_cost(V, dl, own, px, propDisp, pairs, nPair, cull);
+          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0>(V, dl, own, px, propDisp, pairs, nPair, cull);
           ++nCost;
           if (pr.x < currCost && pr.x < costThresh) {
             currCost = pr.x;
@@ -1168,7 +1343,14 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int d = V.dst0 + dl;
   int x, y;
   tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0), tilesX, x, y);
-  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+#if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
+  __shared__ double atanLut[kAtanLutDoubles];
+  atan_lut_fill(atanLut);
+  __syncthreads();
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
+#else
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
+#endif
   unsigned nCost = 0, nPair = 0, nMemo = 0;
   if (x < V.W && y < V.H) {
     const int own = V.dst2src[d];
@@ -1204,7 +1386,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
                 nPair += V.pairCount[(size_t)d * n + idx];
                 ++nMemo;
               } else {
-                r = compute_cost(V, dl, own, px, cand, pairs, nPair, cull);
+                r = compute_cost<DERP_COST_SSD_SCALAR != 0>(V, dl, own, px, cand, pairs, nPair, cull);
               }
               ++nCost;
               if (r.x < bestCost) {
@@ -1351,13 +1533,20 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int dl = d - V.dst0;
   int x, y;
   tile_pixel(blockIdx.x, tilesX, x, y);
-  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x};
+#if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
+  __shared__ double atanLut[kAtanLutDoubles];
+  atan_lut_fill(atanLut);
+  __syncthreads();
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
+#else
+  LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
+#endif
   unsigned nCost = 0, nPair = 0;
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
     const int own = V.dst2src[d];
     PixCtx px;
     load_pixctx(V, d, own, x, y, px);
-    const float2 r = compute_cost(V, dl, own, px, dispIn[(size_t)y * V.W + x], pairs, nPair);
+    const float2 r = compute_cost<DERP_COST_SSD_SCALAR != 0>(V, dl, own, px, dispIn[(size_t)y * V.W + x], pairs, nPair);
     ++nCost;
     costOut[(size_t)y * V.W + x] = r.x;
     confOut[(size_t)y * V.W + x] = r.y;
@@ -1449,16 +1638,22 @@ __global__ void __launch_bounds__(256)
   }
   const int p = blockIdx.z;
   const int T = 16 + 2 * radius;
-  const int n = T * T;
+  // row pitch: the next multiple of 16 texels. A wave reads four rows of 16 lanes; ds_read_b128 serves 16 lanes per
+  // pass (e.g. lanes 0-3, 12-15 of one row with lanes 4-11 of the next), and with 16-byte records those lanes cover
+  // all 64 banks exactly once iff consecutive rows start 0 mod 256 bytes apart (round 3 measured 32 % of the
+  // LDS-active cycles as bank conflicts with pitch T)
+  const int P = (T + 15) & ~15;
+  const int n = P * T;
   // per tile texel one 16-byte record (guide x 3 already scaled by the factor, image): one LDS read per tap
-  float4* tTex = reinterpret_cast<float4*>(ldsTile);  // [n]
+  float4* tTex = reinterpret_cast<float4*>(ldsTile);  // [T rows][P]
   uint8_t* tMask = reinterpret_cast<uint8_t*>(ldsTile + 4 * n);
   const float* img = image + (size_t)p * planeStride;
   const uint8_t* m = mask + (size_t)p * planeStride;
   const size_t gplane = (size_t)(guideIndex ? guideIndex[p] : p) * guideStride;
   const int x0 = blockIdx.x * 16 - radius, y0 = blockIdx.y * 16 - radius;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const int ty = i / T, tx = i - ty * T;
+  for (int k = threadIdx.x; k < T * T; k += 256) {
+    const int ty = k / T, tx = k - ty * T;
+    const int i = ty * P + tx;
     const int sx = min(max(x0 + tx, 0), W - 1), sy = min(max(y0 + ty, 0), H - 1);
     const size_t j = (size_t)sy * W + sx;
     tMask[i] = m[j];
@@ -1478,7 +1673,7 @@ __global__ void __launch_bounds__(256)
   if (x >= W || y >= H) {
     return;
   }
-  const int c = (ly + radius) * T + lx + radius;
+  const int c = (ly + radius) * P + lx + radius;
   const float4 centre = tTex[c];
   float result = centre.w;
   if (tMask[c]) {
@@ -1487,7 +1682,7 @@ __global__ void __launch_bounds__(256)
     const double rcpDenom = 1.0 / (double)denom, rcp3 = 1.0 / 3.0;
     float sumWeight = 0.f, weightedAvg = 0.f;
     for (int v = -radius; v <= radius; ++v) {
-      const int row = c + v * T;
+      const int row = c + v * P;
       for (int u = -radius; u <= radius; ++u) {
         const int j = row + u;
         if (!tMask[j]) {

@@ -1,5 +1,5 @@
 // Cycles per wave64 instruction on one gfx950 SIMD, per instruction class — the calibration behind bench.py's
-// issue-cycle roofline. Every kernel runs ITERS x 64 copies of one instruction over 8 independent
+// issue-cycle roofline. Every kernel runs ITERS x 256 copies of one instruction over 8 independent
 // register chains (throughput) or one chain (dependent latency) on W waves per SIMD of every CU, timed with
 // s_memtime around the loop; cycles per instruction = cycles of the slowest wave / (W x instructions of one wave).
 // One block per CU (the block asks for more than half of the LDS), 256 x W threads = W waves on each SIMD.
@@ -55,9 +55,11 @@ __device__ __forceinline__ unsigned fold(v2f v) { return __float_as_uint(v.x) ^ 
 __device__ __forceinline__ unsigned fold(unsigned long long v) { return (unsigned)v ^ (unsigned)(v >> 32); }
 
 #define X8(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
-#define X64(M) X8(M) X8(M) X8(M) X8(M) X8(M) X8(M) X8(M) X8(M)
+#define X64_(M) X8(M) X8(M) X8(M) X8(M) X8(M) X8(M) X8(M) X8(M)
+#define X64(M) X64_(M) X64_(M) X64_(M) X64_(M)
 #define D8(M) M(0) M(0) M(0) M(0) M(0) M(0) M(0) M(0)
-#define D64(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M)
+#define D64_(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M) D8(M)
+#define D64(M) D64_(M) D64_(M) D64_(M) D64_(M)
 
 // NAME: kernel; T: register type of the chains; OP(i): asm text of one instruction on chain i (%8, %9 = two loop
 // invariant operands of type T, %10 = a per-lane LDS byte address); REP: X64 (throughput) or D64 (latency)
@@ -75,7 +77,7 @@ __device__ __forceinline__ unsigned fold(unsigned long long v) { return (unsigne
       asm volatile(REP(OP) TAIL                                                                                  \
                    : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)              \
                    : "v"(a), "v"(b), "v"(addr)                                                                   \
-                   : "vcc", "s[40:41]", "memory");                                                               \
+                   : "vcc", "s40", "s41", "v100", "v101", "memory");                                                               \
     }                                                                                                            \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                  \
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();                                                  \
@@ -87,8 +89,6 @@ __device__ __forceinline__ unsigned fold(unsigned long long v) { return (unsigne
     }                                                                                                            \
   }
 
-#define S(x) #x
-#define OP2(INS) INS " %" S(i) ", %" S(i) ", %8\n"
 // ---- fp32
 #define O_ADD_F32(i) "v_add_f32 %" #i ", %" #i ", %8\n"
 #define O_MUL_F32(i) "v_mul_f32 %" #i ", %" #i ", %8\n"
@@ -125,8 +125,6 @@ __device__ __forceinline__ unsigned fold(unsigned long long v) { return (unsigne
 #define O_CMP_LT_F64_S(i) "v_cmp_lt_f64 s[40:41], %" #i ", %8\n"
 #define O_LDEXP_F64(i) "v_ldexp_f64 %" #i ", %" #i ", 1\n"
 #define O_FLOOR_F64(i) "v_floor_f64 %" #i ", %" #i "\n"
-#define O_CVT_F32_F64(i) "v_cvt_f32_f64 %" #i ", %8\n"  /* writes the low half of the pair */
-#define O_CVT_F64_F32(i) "v_cvt_f64_f32 %" #i ", %8\n"  /* reads the low half of the pair  */
 // ---- integer / moves / selects (32-bit chains)
 #define O_MOV_B32(i) "v_mov_b32 %" #i ", %8\n"
 #define O_AND_B32(i) "v_and_b32 %" #i ", %" #i ", %8\n"
@@ -140,9 +138,41 @@ __device__ __forceinline__ unsigned fold(unsigned long long v) { return (unsigne
 #define O_CNDMASK_B32(i) "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
 #define O_ADD_CO_U32(i) "v_add_co_u32 %" #i ", vcc, %" #i ", %8\n"
 #define O_READFIRSTLANE(i) "v_readfirstlane_b32 s40, %" #i "\n"
+
+// ---- selects, exec-mask moves, fused-multiply VOP2 forms, cross-lane
+#define O_CNDMASK_E64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[40:41]\n"
+#define O_CMP_CNDMASK(i) "v_cmp_lt_f32 vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
+#define O_CMP_CNDMASK_E64(i) "v_cmp_lt_f32_e64 s[40:41], %" #i ", %8\nv_cndmask_b32_e64 %" #i ", %" #i ", %9, s[40:41]\n"
+#define O_SAVEEXEC_MOV(i) "v_cmp_lt_f32 vcc, %" #i ", %8\ns_and_saveexec_b64 s[40:41], vcc\nv_mov_b32 %" #i ", %9\ns_or_b64 exec, exec, s[40:41]\n"
+#define O_BFI_B32(i) "v_bfi_b32 %" #i ", %8, %" #i ", %9\n"
+#define O_FMAC_F32(i) "v_fmac_f32 %" #i ", %8, %9\n"
+#define O_FMAC_F64(i) "v_fmac_f64 %" #i ", %8, %9\n"
+#define O_SUB_F32(i) "v_sub_f32 %" #i ", %" #i ", %8\n"
+#define O_MIN_F32(i) "v_min_f32 %" #i ", %" #i ", %8\n"
+#define O_OR_B32(i) "v_or_b32 %" #i ", %" #i ", %8\n"
+#define O_XOR_B32(i) "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define O_LSHLREV_B32(i) "v_lshlrev_b32 %" #i ", 1, %" #i "\n"
+#define O_ADD3_U32(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define O_AND_OR_B32(i) "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define O_MAX_I32(i) "v_max_i32 %" #i ", %" #i ", %8\n"
+#define O_ADDC_CO_U32(i) "v_addc_co_u32 %" #i ", vcc, %" #i ", %8, vcc\n"
+#define O_MOV_DPP(i) "v_mov_b32_dpp %" #i ", %" #i " row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define O_ADD_F32_DPP(i) "v_add_f32_dpp %" #i ", %" #i ", %8 row_shr:1 row_mask:0xf bank_mask:0xf\n"
+#define O_PK_MOV_B32(i) "v_pk_mov_b32 %" #i ", %" #i ", %8 op_sel:[1,0]\n"
+#define O_MOV_B64(i) "v_mov_b64 %" #i ", %8\n"
+#define O_LSHL_ADD_U64(i) "v_lshl_add_u64 %" #i ", %" #i ", 3, %8\n"
+#define O_MUL_F64_S(i) "v_mul_f64 %" #i ", %" #i ", s[40:41]\n"
+#define O_DS_READ_B128(i) "ds_read_b64 %" #i ", %10\n"
+#define O_DS_BPERMUTE(i) "ds_bpermute_b32 %" #i ", %10, %" #i "\n"
+// mixed streams: the shape of the SSD block (per 8: 3 pk_mul, 2 pk_add / add, 2 cvt, 1 trunc)
+#define O_MIX_FMA64_ADD32(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\nv_mov_b32 v100, v101\n"
+#define O_MIX_FMA64_SMOV(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\ns_mov_b32 s40, 5\n"
+#define O_MIX_FMA64_2SMOV(i) "v_fma_f64 %" #i ", %" #i ", %8, %9\ns_mov_b32 s40, 5\ns_mov_b32 s41, 6\n"
+#define O_MIX_TRUNC_ADD32(i) "v_trunc_f32 %" #i ", %" #i "\nv_add_f32 %" #i ", %" #i ", %8\n"
+#define O_MIX_ADD32_MUL32(i) "v_mul_f32 %" #i ", %" #i ", %8\nv_add_f32 %" #i ", %" #i ", %9\n"
 // ---- 64-bit integer chains
 #define O_LSHLREV_B64(i) "v_lshlrev_b64 %" #i ", 1, %" #i "\n"
-#define O_MAD_U64_U32(i) "v_mad_u64_u32 %" #i ", vcc, %8, %9, %" #i "\n"  /* reads the low halves of %8, %9 */
+#define O_MAD_U64_U32(i) "v_mad_u64_u32 %" #i ", vcc, s40, 5, %" #i "\n"
 // ---- LDS (8-byte slots, lane-linear: conflict free). Latency: the loaded value is the next address.
 #define O_DS_READ_B64(i) "ds_read_b64 %" #i ", %10\n"
 #define O_DS_WRITE_B64(i) "ds_write_b64 %10, %" #i "\n"
@@ -182,8 +212,6 @@ KERNEL(k_cmp_lt_f64, double, O_CMP_LT_F64, X64, "")
 KERNEL(k_cmp_lt_f64_sgpr, double, O_CMP_LT_F64_S, X64, "")
 KERNEL(k_ldexp_f64, double, O_LDEXP_F64, X64, "")
 KERNEL(k_floor_f64, double, O_FLOOR_F64, X64, "")
-KERNEL(k_cvt_f32_f64, double, O_CVT_F32_F64, X64, "")
-KERNEL(k_cvt_f64_f32, double, O_CVT_F64_F32, X64, "")
 KERNEL(k_mov_b32, unsigned, O_MOV_B32, X64, "")
 KERNEL(k_and_b32, unsigned, O_AND_B32, X64, "")
 KERNEL(k_lshrrev_b32, unsigned, O_LSHRREV_B32, X64, "")
@@ -200,6 +228,35 @@ KERNEL(k_lshlrev_b64, unsigned long long, O_LSHLREV_B64, X64, "")
 KERNEL(k_mad_u64_u32, unsigned long long, O_MAD_U64_U32, X64, "")
 KERNEL(k_ds_read_b64, unsigned long long, O_DS_READ_B64, X64, WAIT_LGKM)
 KERNEL(k_ds_write_b64, unsigned long long, O_DS_WRITE_B64, X64, WAIT_LGKM)
+
+KERNEL(k_cndmask_e64, unsigned, O_CNDMASK_E64, X64, "")
+KERNEL(k_cmp_cndmask, float, O_CMP_CNDMASK, X64, "")
+KERNEL(k_cmp_cndmask_e64, float, O_CMP_CNDMASK_E64, X64, "")
+KERNEL(k_saveexec_mov, float, O_SAVEEXEC_MOV, X64, "")
+KERNEL(k_bfi_b32, unsigned, O_BFI_B32, X64, "")
+KERNEL(k_fmac_f32, float, O_FMAC_F32, X64, "")
+KERNEL(k_fmac_f64, double, O_FMAC_F64, X64, "")
+KERNEL(k_sub_f32, float, O_SUB_F32, X64, "")
+KERNEL(k_min_f32, float, O_MIN_F32, X64, "")
+KERNEL(k_or_b32, unsigned, O_OR_B32, X64, "")
+KERNEL(k_xor_b32, unsigned, O_XOR_B32, X64, "")
+KERNEL(k_lshlrev_b32, unsigned, O_LSHLREV_B32, X64, "")
+KERNEL(k_add3_u32, unsigned, O_ADD3_U32, X64, "")
+KERNEL(k_and_or_b32, unsigned, O_AND_OR_B32, X64, "")
+KERNEL(k_max_i32, unsigned, O_MAX_I32, X64, "")
+KERNEL(k_addc_co_u32, unsigned, O_ADDC_CO_U32, X64, "")
+KERNEL(k_mov_dpp, unsigned, O_MOV_DPP, X64, "")
+KERNEL(k_add_f32_dpp, float, O_ADD_F32_DPP, X64, "")
+KERNEL(k_pk_mov_b32, v2f, O_PK_MOV_B32, X64, "")
+KERNEL(k_mov_b64, double, O_MOV_B64, X64, "")
+KERNEL(k_lshl_add_u64, unsigned long long, O_LSHL_ADD_U64, X64, "")
+KERNEL(k_mul_f64_sgpr, double, O_MUL_F64_S, X64, "")
+KERNEL(k_ds_bpermute, unsigned, O_DS_BPERMUTE, X64, WAIT_LGKM)
+KERNEL(k_mix_fma64_add32, double, O_MIX_FMA64_ADD32, X64, "")
+KERNEL(k_mix_fma64_smov, double, O_MIX_FMA64_SMOV, X64, "")
+KERNEL(k_mix_fma64_2smov, double, O_MIX_FMA64_2SMOV, X64, "")
+KERNEL(k_mix_trunc_add32, float, O_MIX_TRUNC_ADD32, X64, "")
+KERNEL(k_mix_add32_mul32, float, O_MIX_ADD32_MUL32, X64, "")
 // dependent chains (latency)
 KERNEL(k_dep_fma_f32, float, O_FMA_F32, D64, "")
 KERNEL(k_dep_mul_f32, float, O_MUL_F32, D64, "")
@@ -253,11 +310,18 @@ static const Entry kEntries[] = {
     E(k_fma_f64, "f64"), E(k_max_f64, "f64"), E(k_rcp_f64, "trans_f64"), E(k_rsq_f64, "trans_f64"),
     E(k_sqrt_f64, "trans_f64"), E(k_div_scale_f64, "f64"), E(k_div_fmas_f64, "f64"), E(k_div_fixup_f64, "f64"),
     E(k_cmp_lt_f64, "f64"), E(k_cmp_lt_f64_sgpr, "f64"), E(k_ldexp_f64, "f64"), E(k_floor_f64, "f64"),
-    E(k_cvt_f32_f64, "cvt"), E(k_cvt_f64_f32, "cvt"), E(k_mov_b32, "int32"), E(k_and_b32, "int32"),
+    E(k_mov_b32, "int32"), E(k_and_b32, "int32"),
     E(k_lshrrev_b32, "int32"), E(k_add_u32, "int32"), E(k_lshl_add_u32, "int32"), E(k_bfe_u32, "int32"),
     E(k_perm_b32, "int32"), E(k_mul_lo_u32, "int32"), E(k_mul_hi_u32, "int32"), E(k_cndmask_b32, "int32"),
     E(k_add_co_u32, "int32"), E(k_readfirstlane, "int32"), E(k_lshlrev_b64, "int64"), E(k_mad_u64_u32, "int64"),
     E(k_ds_read_b64, "lds"), E(k_ds_write_b64, "lds"),
+    E(k_cndmask_e64, "int32"), E(k_cmp_cndmask, "pair"), E(k_cmp_cndmask_e64, "pair"), E(k_saveexec_mov, "pair"),
+    E(k_bfi_b32, "int32"), E(k_fmac_f32, "f32"), E(k_fmac_f64, "f64"), E(k_sub_f32, "f32"), E(k_min_f32, "f32"),
+    E(k_or_b32, "int32"), E(k_xor_b32, "int32"), E(k_lshlrev_b32, "int32"), E(k_add3_u32, "int32"),
+    E(k_and_or_b32, "int32"), E(k_max_i32, "int32"), E(k_addc_co_u32, "int32"), E(k_mov_dpp, "int32"),
+    E(k_add_f32_dpp, "f32"), E(k_pk_mov_b32, "int32"), E(k_mov_b64, "int32"), E(k_lshl_add_u64, "int64"),
+    E(k_mul_f64_sgpr, "f64"), E(k_ds_bpermute, "lds"), E(k_mix_fma64_add32, "pair"), E(k_mix_fma64_smov, "pair"),
+    E(k_mix_fma64_2smov, "pair"), E(k_mix_trunc_add32, "pair"), E(k_mix_add32_mul32, "pair"),
     L(k_dep_fma_f32, "f32"), L(k_dep_mul_f32, "f32"), L(k_dep_pk_mul_f32, "pk_f32"), L(k_dep_fma_f64, "f64"),
     L(k_dep_add_f64, "f64"), L(k_dep_rcp_f64, "trans_f64"), L(k_dep_ds_read_b32, "lds"),
 };
@@ -265,7 +329,7 @@ static const Entry kEntries[] = {
 int main(int argc, char** argv) {
   bool classes = false;
   const char* only = nullptr;
-  int iters = 256;
+  int iters = 128;
   for (int i = 1; i < argc; ++i) {
     if (!strcmp(argv[i], "--classes")) {
       classes = true;
@@ -285,7 +349,7 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"iters\": %d, \"insts_per_iter\": 64}\n", prop.name, cus,
+  printf("{\"device\": \"%s\", \"cus\": %d, \"clock_khz\": %d, \"iters\": %d, \"insts_per_iter\": 256}\n", prop.name, cus,
          prop.clockRate, iters);
   for (const Entry& e : kEntries) {
     if (only && !strstr(e.name, only)) {
@@ -315,7 +379,7 @@ int main(int argc, char** argv) {
         mx = h[2 * i] > mx ? h[2 * i] : mx;
         sum += h[2 * i];
       }
-      const double n = (double)iters * 64;
+      const double n = (double)iters * 256;
       // s_memtime ticks per instruction issued on the SIMD (w waves share it)
       printf("{\"op\": \"%s\", \"class\": \"%s\", \"mode\": \"%s\", \"waves_per_simd\": %d, \"ticks_per_inst_max\": %.3f, "
              "\"ticks_per_inst_mean\": %.3f, \"kernel_ms\": %.4f, \"ns_per_inst\": %.4f}\n",

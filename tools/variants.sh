@@ -7,7 +7,7 @@ for lib in facebook360_dep_amd/libderp_var_*.so; do
   name=$(basename $lib .so)
   if [ -z "$VARIANTS_NO_PARITY" ]; then
     DERP_LIB=$PWD/$lib timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu \
-      -k "cost_map or brute_force or random_proposals or full_pyramid or config1_full or option_matrix" > gpurun_out/var_$name.pytest 2>&1
+      -k "cost_map or brute_force or random_proposals or full_pyramid or config1_full or option_matrix or lean_atan2" > gpurun_out/var_$name.pytest 2>&1
     echo "$name parity: $(tail -1 gpurun_out/var_$name.pytest)"
   fi
   DERP_LIB=$PWD/$lib timeout 600 python bench.py --frames 2 --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame "$@" > /tmp/v.json 2>/tmp/v.err || { echo "$lib FAILED"; tail -3 /tmp/v.err; continue; }
