@@ -46,6 +46,10 @@ def parse():
                     help="where the synthetic frames are rendered: cuda (default, fast) | cpu (bit-identical to the frames "
                          "the CPU tests render, so result_crc can be compared with the oracle's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "full", "sample"],
+                    help="the CPU oracle on frame 0 of the workload: full = every level measured (about 2.5 minutes for "
+                         "16 x 2048^2 on 16 CPUs), sample = levels 9..2 measured and levels 1-0 extrapolated by pixel "
+                         "count (about 10 s), auto = full when this process may use >= 16 CPUs")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the config-2 single-frame leg at N = 1")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--exchange", default="rccl,torch,broadcast",
@@ -98,10 +102,10 @@ def b_alg(n_cost, n_pair):
     return 64.0 * n_cost + 272.0 * n_pair
 
 
-def cpu_baseline(rig, sizes, frame, res, n_cams):
-    """the CPU oracle ("port") on this host's cores. Config 1 in full; config 2's own frame
-    with levels 9..2 measured and levels 1-0 extrapolated from level 2's time per pixel (the full-size
-    levels would take minutes). Returns the cpu_baseline object."""
+def cpu_baseline(rig, sizes, frame, res, n_cams, mode="auto"):
+    """the CPU oracle ("port") on this host's cores. Config 1 in full; frame 0 of the bench rig either
+    in full (every level measured: `extrapolated` false) or, on a host with few CPUs, with levels 9..2 measured and
+    levels 1-0 extrapolated from level 2's time per pixel. Returns the cpu_baseline object."""
     import numpy as np  # noqa: F401
 
     from facebook360_dep_amd import synth
@@ -124,7 +128,8 @@ def cpu_baseline(rig, sizes, frame, res, n_cams):
     out["config1_full"] = {"value": round(n1 * r1 * r1 / t1 / 1e6, 4), "seconds": round(t1, 2),
                            "workload": "BASELINE config 1 in full: 4 x 512^2, %d levels" % len(sizes1)}
     # --- the bench rig: coarse levels measured, the finest extrapolated
-    first_measured = next((lv for lv, (w, h) in enumerate(sizes) if w <= 512), len(sizes) - 1)
+    full = mode == "full" or (mode == "auto" and cores >= 16)
+    first_measured = 0 if full else next((lv for lv, (w, h) in enumerate(sizes) if w <= 512), len(sizes) - 1)
     t_levels = {}
     prev = None
     for level in range(len(sizes) - 1, first_measured - 1, -1):
@@ -145,15 +150,18 @@ def cpu_baseline(rig, sizes, frame, res, n_cams):
                      "Not the timed workload itself: one frame, no temporal filter."
                      % (n_cams, w0, h0, len(sizes) - 1, first_measured, measured, cores, first_measured - 1,
                         first_measured, extra, total)) if first_measured > 0 else (
-        "frame 0 of the bench workload in full: %.1f s on %d threads" % (measured, cores))
+        "frame 0 of the bench workload (%d cameras, %dx%d) in full, all %d levels measured in this run: %.1f s on %d CPUs "
+        "(%d threads). Not the timed workload itself: one frame, no temporal filter." % (n_cams, w0, h0, len(sizes), measured,
+                                                                                        cores, threads))
     out["extrapolated"] = first_measured > 0
     out["measured_seconds"] = round(measured, 2)
-    # the same frame run in FULL once (tools/oracle_full_frame.py, committed under profiles/): quoted beside the
-    # extrapolation so that the two can be compared
-    full = os.path.join(ROOT, "profiles", "oracle_full_frame.json")
-    if os.path.exists(full):
+    out["level_seconds"] = {str(lv): round(t, 3) for lv, t in sorted(t_levels.items())}
+    # the same frame run in full in an earlier round (tools/oracle_full_frame.py, committed under profiles/): quoted
+    # beside an extrapolated value so that the two can be compared
+    once = os.path.join(ROOT, "profiles", "oracle_full_frame.json")
+    if not full and os.path.exists(once):
         try:
-            with open(full) as f:
+            with open(once) as f:
                 out["full_frame_measured_once"] = json.load(f)
         except Exception:  # noqa: BLE001
             pass
@@ -312,29 +320,47 @@ def main():
     exec_frac = 1.0 - memo / n_cost_launch if n_cost_launch else 1.0
     alg_bytes_exec = b_alg(n_cost_launch, n_pair_launch) * exec_frac
     kernel_s = kernel_ms * 1e-3
-    valu_cycles = prof.get("ping_pong_level0_valu_busy_cycles_per_launch")  # SQ_ACTIVE_INST_VALU x 4 (quad-cycles)
-    achieved = valu_cycles / kernel_s / 1e9 if valu_cycles and kernel_s > 0 else None
+    # VALU issue cycles of one level-0 launch: rocprofv3's typed instruction counters priced per instruction class at
+    # the issue intervals tools/valu_ubench.hip measured on this chip (tools/valu_model.py; round 3 charged every
+    # instruction 4 cycles / summed a per-wave busy counter, which read above 1 for some kernels)
+    issue_cycles = prof.get("ping_pong_level0_issue_cycles_per_launch")
+    issue_low = prof.get("ping_pong_level0_issue_cycles_if_simple_ops_coissue")
+    achieved = issue_cycles / kernel_s / 1e9 if issue_cycles and kernel_s > 0 else None
     traffic = prof.get("ping_pong_level0_hbm_bytes_per_launch")
+    # the arithmetic the reference's algorithm needs for the executed (call, source) pairs, at the same class costs
+    alg_valu = None
+    cc = prof.get("ping_pong_level0_class_cycles")
+    if cc and kernel_s > 0:
+        per_pair = 372.0 * cc["S"] + 90.0 * cc["F"] + 84.0 * cc["D"] + 3.0 * cc["T64"]  # tools/valu_model.py ALG_PER_PAIR
+        alg_valu = {"cycles_per_pair": round(per_pair, 1),
+                    "frac": round(n_pair_launch * exec_frac * per_pair / 64.0 / kernel_s / 1e9 / VALU_PEAK_GCYC, 4),
+                    "note": "operations computeSSD + Camera::sees need per executed (cost call, source) pair (372 plain fp32, "
+                            "90 conversions / truncations, 84 fp64, 3 fp64 transcendental; tools/valu_model.py) x pairs / 64 "
+                            "lanes, priced like the executed instructions: what an instruction-perfect kernel would issue"}
     roofline = {
         "kernel": "k_ping_pong @ level 0",
         "bound": "valu",
         "achieved": round(achieved, 1) if achieved else None,
         "peak": VALU_PEAK_GCYC,
-        "unit": "G VALU-busy SIMD-cycles/s",
+        "unit": "G SIMD issue-cycles/s",
         "frac": round(achieved / VALU_PEAK_GCYC, 4) if achieved else None,
         "traffic": traffic,
         "kernel_ms": round(kernel_ms, 3),
         "launches_timed": pp["launches"],
-        "note": ("achieved = SQ_ACTIVE_INST_VALU of one level-0 launch (rocprofv3 --pmc on this bench, "
-                 "profiles/valu_roofline.json; quad-cycles x 4) / this run's HIP-event launch duration; peak = "
-                 "%d SIMDs x %.1f GHz. The kernel gathers from L1/L2-resident tables: HBM is not its bound "
-                 "(hbm_frac below), VALU issue is." % (N_SIMD, PEAK_CLOCK_GHZ)),
+        "note": ("achieved = sum over instruction classes of (instructions of one level-0 launch, rocprofv3 typed VALU "
+                 "counters) x (issue cycles per wave64 instruction of that class, measured by tools/valu_ubench.hip at the "
+                 "kernel's waves per SIMD: plain fp32 add/mul, moves, logic 2.1-2.8; other 32-bit 4.2; fp64 and packed "
+                 "fp32 4.4; fp64 rcp/rsq/sqrt 16) / this run's HIP-event launch duration; peak = %d SIMDs x %.1f GHz. "
+                 "The kernel gathers from L1/L2-resident tables: HBM is not its bound (hbm_frac below), VALU issue is."
+                 % (N_SIMD, PEAK_CLOCK_GHZ)),
         "stale": stale,
-        "valu_busy_frac_at_measured_clock": prof.get("ping_pong_level0_valu_busy_frac"),
-        # second numerator (VALU wave-instructions x 4 cycles); see profiles/README.md for how the two relate
-        "frac_by_instruction_count": (round(prof["ping_pong_level0_valu_insts_x4_cycles_per_launch"] / kernel_s / 1e9
-                                            / VALU_PEAK_GCYC, 4)
-                                      if prof.get("ping_pong_level0_valu_insts_x4_cycles_per_launch") and kernel_s > 0 else None),
+        # plain fp32 / move / logic instructions can issue beside a 4-cycle instruction of another wave (two 16-lane
+        # halves per SIMD): if every one of them found such a slot the pipe time would be this much
+        "frac_if_simple_ops_coissue": (round(issue_low / kernel_s / 1e9 / VALU_PEAK_GCYC, 4)
+                                       if issue_low and kernel_s > 0 else None),
+        "algorithmic_valu": alg_valu,
+        # NOT a roofline (round 3's figure): VALU-active quad-cycles summed over the resident waves / chip cycles
+        "occupancy_valu_busy_NOT_A_BOUND": prof.get("ping_pong_level0_valu_busy_frac"),
         "waves_per_simd": prof.get("ping_pong_level0_waves_per_simd"),
         "wave_issue_breakdown": prof.get("ping_pong_level0_wave_cycle_shares"),
         "hbm_traffic_GBps": round(traffic / kernel_s / 1e9, 1) if traffic and kernel_s > 0 else None,
@@ -431,7 +457,7 @@ def main():
             "workload": "BASELINE config 2: %d-camera %dx%d rig, single frame, full %d-level pyramid, no temporal filter"
                         % (n_cams, res, res, n_levels)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and frame0 is not None:
-        out["cpu_baseline"] = cpu_baseline(rig, sizes, frame0, res, n_cams)
+        out["cpu_baseline"] = cpu_baseline(rig, sizes, frame0, res, n_cams, args.cpu_baseline)
     runner.close()
     g.close()
     if rank == 0:

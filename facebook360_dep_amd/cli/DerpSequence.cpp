@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include "derp_job.h"
+#include "rendezvous.h"
 
 using namespace cli;
 
@@ -50,6 +51,7 @@ struct FileTransport {
   derp_ctx* ctx;
   int rank, world, first, last, radius, partition;
   fs::path dir;
+  std::string token;  // the launch's rendezvous token: every halo file starts with it
   std::vector<derp_seq_transfer> plan;
   std::vector<char> buf;
   double seconds = 0;
@@ -79,6 +81,7 @@ struct FileTransport {
       const fs::path dst = name(level, kind, t), tmp = dst.string() + ".tmp";
       {
         std::ofstream f(tmp, std::ios::binary);
+        f.write(token.data(), (std::streamsize)token.size());
         f.write(buf.data(), (std::streamsize)bytes);
         CHECK_MSG(f.good(), "failed to write " + tmp.string());
       }
@@ -101,6 +104,10 @@ struct FileTransport {
       buf.resize(bytes);
       {
         std::ifstream f(src, std::ios::binary);
+        std::string head(token.size(), '\0');
+        f.read(&head[0], (std::streamsize)head.size());
+        CHECK_MSG(f.gcount() == (std::streamsize)head.size() && head == token,
+                  "halo file of another launch (stale?): " + src.string());
         f.read(buf.data(), (std::streamsize)bytes);
         CHECK_MSG(f.gcount() == (std::streamsize)bytes, "short read from " + src.string());
       }
@@ -126,7 +133,7 @@ int main(int argc, char** argv) {
   F.boolean("do_temporal_masking", false, "use foreground masks in the temporal filter [extension: pipeline.py do_temporal_masking]");
   F.dbl("sigma", 0.01, "spatio-temporal smoothing [extension: TemporalBilateralFilter --sigma]");
   F.i32("space_radius", -1, "space filtering radius [extension: TemporalBilateralFilter --space_radius]");
-  F.i32("time_radius", 2, "temporal filtering radius, at most 15 [extension: TemporalBilateralFilter --time_radius]");
+  F.i32("time_radius", 2, "temporal filtering radius [extension: TemporalBilateralFilter --time_radius]");
   F.dbl("weight_b", 0.5, "Blue channel weight [extension: TemporalBilateralFilter --weight_b]");
   F.dbl("weight_g", 1.0, "Green channel weight [extension: TemporalBilateralFilter --weight_g]");
   F.dbl("weight_r", 1.0, "Red channel weight [extension: TemporalBilateralFilter --weight_r]");
@@ -148,18 +155,10 @@ int main(int argc, char** argv) {
   // ---- ranks: --gpus forks them; otherwise RANK / WORLD_SIZE / LOCAL_RANK from the environment
   int rank = env_int("RANK", 0), world = env_int("WORLD_SIZE", 1), localRank = env_int("LOCAL_RANK", -1);
   std::string idFile = F.s("rccl_id_file");
-  // a nonce every rank of ONE job agrees on: a stale id file of an earlier job is told apart by it
-  std::string nonce = std::string(getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "") + ":" +
-                      (getenv("TORCHELASTIC_RUN_ID") ? getenv("TORCHELASTIC_RUN_ID") : "");
   if (F.i("gpus") > 1 && world == 1) {
     world = F.i("gpus");
     CHECK_MSG(F.s("output_root") != "", "output_root");
     fs::create_directories(F.s("output_root"));
-    if (idFile.empty()) {
-      idFile = (fs::path(F.s("output_root")) / fmt(".derp_rccl_id.%d", (int)getpid())).string();
-    }
-    nonce = fmt("pid%d:%ld", (int)getpid(), (long)time(nullptr));
-    fs::remove(idFile);
     std::vector<pid_t> kids;
     for (int r = 0; r < world; ++r) {  // fork before any HIP call
       const pid_t pid = fork();
@@ -188,7 +187,10 @@ int main(int argc, char** argv) {
           }
         }
       }
-      fs::remove(idFile);
+      {
+        std::error_code ec;
+        fs::remove_all(fs::path(F.s("output_root")) / ".derp_seq", ec);  // rendezvous files (and, after a failure, halo files)
+      }
       if (failed) {
         LOG_FATAL(fmt("%d of %d ranks failed", failed, world));
       }
@@ -205,7 +207,7 @@ int main(int argc, char** argv) {
   DerpJob J(F);
   J.setup_host();
   CHECK_MSG(F.s("partition") == "block" || F.s("partition") == "cyclic", "partition is block or cyclic");
-  CHECK_MSG(F.i("time_radius") >= 0 && F.i("time_radius") <= 15, "time_radius in 0..15 (the filter kernel's window holds 31 frames)");
+  CHECK_MSG(F.i("time_radius") >= 0, "time_radius >= 0");
   const int partition = F.s("partition") == "block" ? DERP_SEQ_BLOCK : DERP_SEQ_CYCLIC;
   const int first = J.firstFrame, last = J.firstFrame + J.numFrames - 1;
   std::vector<int> owned;
@@ -220,14 +222,17 @@ int main(int argc, char** argv) {
   // frame by frame (the order the level loop consumes them in)
   IoPool pool(F.i("threads"));
   FrameStore store(J, pool, owned);
+  // (with --resident_frames the library streams from the decoded buffers for the whole run: no throttling then)
+  store.throttle = !(F.i("resident_frames") > 0 && F.i("resident_frames") < nOwned);
   for (int level = store.inTop; level > J.levelEnd; --level) {
     for (int k = 0; k < nOwned; ++k) {
-      store.start_decode(k, level);
+      store.schedule(k, level);
     }
   }
   for (int k = 0; k < nOwned; ++k) {
-    store.start_decode(k, J.levelEnd);
+    store.schedule(k, J.levelEnd);
   }
+  store.pump();
 
   const double tHost = total.s();
   // DERP_SINGLE_DEVICE: every rank on --device (several ranks sharing one GPU: tests on a one-GPU box)
@@ -259,49 +264,71 @@ int main(int argc, char** argv) {
 
   CHECK_MSG(F.s("exchange") == "rccl" || F.s("exchange") == "files", "exchange is rccl or files");
   bool useFiles = world > 1 && F.s("exchange") == "files";
+  Rendezvous rv;
+  rv.dir = fs::path(J.outputRoot) / ".derp_seq";
+  rv.rank = rank;
+  rv.world = world;
+  if (world > 1) {
+    rv.join();  // a token of THIS launch on every rank; whatever an earlier job left under .derp_seq is gone
+  }
   if (world > 1 && !useFiles) {  // RCCL communicator: rank 0 publishes the unique id through a file
-    CHECK_MSG(!idFile.empty(), "--rccl_id_file (a path every rank can read) is needed when WORLD_SIZE > 1");
-    // file = [128-byte id][nonce]: ranks started by hand (RANK / WORLD_SIZE) may find the file of an earlier job
-    // under the same name; they wait until the nonce is this job's
+    if (idFile.empty()) {
+      idFile = (rv.dir / "rccl_id").string();
+    }
+    // Every step whose failure on ONE rank would leave the others blocked is agreed on first: can every rank load
+    // librccl at all (ncclCommInitRank is a rendezvous: a rank that never calls it hangs the rest)?
     unsigned char id[128];
-    if (rank == 0) {
-      fs::remove(idFile);
-      CHECK_MSG(derp_rccl_unique_id(id, sizeof id) == 0, "ncclGetUniqueId failed (librccl not loadable?)");
-      const std::string tmp = idFile + ".tmp";
-      {
-        std::ofstream f(tmp, std::ios::binary);
-        f.write(reinterpret_cast<const char*>(id), sizeof id);
-        f.write(nonce.data(), (std::streamsize)nonce.size());
-      }
-      fs::rename(tmp, idFile);
-    } else {
-      Timer t;
-      for (;;) {
-        std::error_code ec;
-        if (fs::exists(idFile, ec) && fs::file_size(idFile, ec) == sizeof id + nonce.size()) {
-          std::ifstream f(idFile, std::ios::binary);
-          std::string got(nonce.size(), '\0');
-          f.read(reinterpret_cast<char*>(id), sizeof id);
-          f.read(&got[0], (std::streamsize)got.size());
-          if (f && got == nonce) {
-            break;
-          }
-        }
-        CHECK_MSG(t.s() < 300, "timed out waiting for " + idFile);
-        usleep(20000);
-      }
-    }
-    // every rank sees the same refusal (e.g. "duplicate GPU": two ranks on one device), so every rank falls back
-    if (derp_seq_attach_rccl(seq, id, sizeof id) != 0 || derp_seq_selftest(seq, 4096) != 0) {
-      LOG_WARNING(std::string("RCCL transport unavailable (") + derp_last_error(ctx) + "); exchanging the halo frames through files");
+    const bool loadable = derp_rccl_unique_id(id, sizeof id) == 0;  // binds the library; rank 0 keeps this id
+    const int canLoad = rv.agree("rccl_load", loadable);
+    if (canLoad != 1) {
+      LOG_WARNING(fmt("RCCL transport unavailable (librccl cannot be loaded on %s rank); exchanging the halo frames "
+                      "through files", canLoad == 0 ? "any" : "some"));
       useFiles = true;
-    }
-    if (rank == 0 && F.i("gpus") <= 1) {
-      fs::remove(idFile);  // every rank has joined the communicator: the next job must not find this id
+    } else {
+      // file = [128-byte id][token]: only this launch's token makes it this launch's id
+      if (rank == 0) {
+        const std::string tmp = idFile + ".tmp";
+        {
+          std::ofstream f(tmp, std::ios::binary);
+          f.write(reinterpret_cast<const char*>(id), sizeof id);
+          f.write(rv.token.data(), (std::streamsize)rv.token.size());
+        }
+        fs::rename(tmp, idFile);
+      } else {
+        Timer t;
+        for (;;) {
+          std::error_code ec;
+          if (fs::exists(idFile, ec) && fs::file_size(idFile, ec) == sizeof id + rv.token.size()) {
+            std::ifstream f(idFile, std::ios::binary);
+            std::string got(rv.token.size(), '\0');
+            f.read(reinterpret_cast<char*>(id), sizeof id);
+            f.read(&got[0], (std::streamsize)got.size());
+            if (f && got == rv.token) {
+              break;
+            }
+          }
+          CHECK_MSG(t.s() < 300, "timed out waiting for " + idFile);
+          usleep(20000);
+        }
+      }
+      const bool attached = derp_seq_attach_rccl(seq, id, sizeof id) == 0 && derp_seq_selftest(seq, 4096) == 0;
+      const std::string why = attached ? "" : derp_last_error(ctx);
+      // all ranks use RCCL or all ranks use files: a rank that switched alone would leave its peers in a collective
+      const int all = rv.agree("rccl_attach", attached);
+      if (all == 1) {
+        if (rank == 0) {
+          std::error_code ec;
+          fs::remove(idFile, ec);  // every rank has joined the communicator: nobody needs the id any more
+        }
+      } else {
+        LOG_WARNING("RCCL transport unavailable (" + (why.empty() ? std::string("another rank could not attach") : why) +
+                    "); exchanging the halo frames through files");
+        useFiles = true;
+      }
     }
   }
   FileTransport files{seq, ctx, rank, world, first, last, so.do_temporal_filter ? so.time_radius : 0, partition,
-                      fs::path(J.outputRoot) / (".halo_" + std::to_string(std::hash<std::string>{}(nonce) % 100000000))};
+                      rv.dir / "halo", rv.token};
   if (useFiles) {
     DERP_OK(ctx, derp_seq_attach_external(seq));
     files.init();
@@ -324,12 +351,35 @@ int main(int argc, char** argv) {
   }
   for (int level = J.levelStart; level >= J.levelEnd; --level) {
     LOG_INFO(fmt("Processing level %d of %d frame(s)", level, nOwned));
+    const int parity = level & 1;
+    const size_t frameBytes = J.npx(level) * 4 * J.D;
+    writer.begin(parity, frameBytes * std::max(nOwned, 1));
+    // A frame is filtered as soon as its window is computed (derp_seq_level_filter_frame) and its files leave one
+    // frame later, from the filter's scratch over the copy stream — behind the compute of the frames that follow,
+    // instead of all at once after the level's last frame (at the finest level that was 4.3 GB of PFMs and most of a
+    // second at the very end of the job). What the two directories receive is the same filtered level either way.
+    int nFiltered = 0, nSaved = 0;
     for (int k = 0; k < nOwned; ++k) {
       store.wait(k, level);  // this frame's level is decoded (the pool is busy with later frames / finer levels)
       Timer t;
       store.hand_over(seq, k, level, nSlots >= nOwned);
       tUpload += t.s();
       DERP_OK(ctx, derp_seq_level_compute_frame(seq, level, owned[k]));
+      if (so.do_temporal_filter) {
+        const int ready = nFiltered;  // filtered in an earlier iteration: their kernels ran before this frame's compute
+        while (nFiltered < nOwned) {
+          const int rc = derp_seq_level_filter_frame(seq, level, owned[nFiltered]);
+          if (rc == 2) {
+            break;
+          }
+          DERP_OK(ctx, rc);
+          ++nFiltered;
+        }
+        for (; nSaved < ready; ++nSaved) {
+          writer.save_seq(seq, owned[nSaved], parity, frameBytes * nSaved, level, zero_pad(owned[nSaved]), dirs,
+                          level == J.levelEnd, true);
+        }
+      }
     }
     {
       Timer t;
@@ -354,19 +404,18 @@ int main(int argc, char** argv) {
       DERP_OK(ctx, derp_synchronize(ctx));
       tCompute += t.s();
     }
-    const int parity = level & 1;
-    writer.begin(parity, J.npx(level) * 4 * J.D * std::max(nOwned, 1));
-    for (int k = 0; k < nOwned; ++k) {
+    for (int k = nSaved; k < nOwned; ++k) {
       // PNG only at the finest level: the pipeline forces PFM above it (pipeline.py:366-369)
-      writer.save_seq(seq, owned[k], parity, J.npx(level) * 4 * J.D * k, level, zero_pad(owned[k]), dirs, level == J.levelEnd);
+      writer.save_seq(seq, owned[k], parity, frameBytes * k, level, zero_pad(owned[k]), dirs, level == J.levelEnd);
     }
     LOG_INFO(fmt("-- Elapsed time: %.3fs wall (level %d)", total.s(), level));
   }
   writer.finish();
   if (useFiles) {
-    std::error_code ec;
-    fs::remove(files.dir, ec);  // empty by now (every file is removed by its reader); ranks race harmlessly
     LOG_INFO(fmt("-- rank %d: halo exchange through files: %.1f MB received, %.3fs", rank, files.received / 1e6, files.seconds));
+  }
+  if (world > 1) {
+    rv.leave();
   }
   uint64_t sent = 0, received = 0;
   double exchangeMs = 0;

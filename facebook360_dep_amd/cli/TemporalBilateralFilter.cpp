@@ -70,7 +70,7 @@ int main(int argc, char** argv) {
   if (F.s("disparity").empty()) {
     F.set("disparity", F.s("output_root") + "/disparity_levels");
   }
-  CHECK_MSG(2 * F.i("time_radius") + 1 <= 31, "time_radius <= 15 (window of at most 31 frames)");
+  CHECK_MSG(F.i("time_radius") >= 0, "time_radius >= 0");
   const std::vector<derp_camera_desc> rigSrc = load_rig(F.s("rig"));
   const std::vector<derp_camera_desc> rigDst = filter_destinations(rigSrc, F.s("cameras"));
   CHECK_MSG(!rigDst.empty(), "no destination cameras!");

@@ -869,7 +869,10 @@ inline bool exr_size(const fs::path& path, int& w, int& h) {
   head.resize((size_t)f.gcount());
   ExrInfo info;
   if (!exr_header(head, path, info, false)) {
-    return false;
+    // a header longer than the first 4 KB (many attributes) is still a valid file: parse all of it before giving up
+    if (head.size() < 4096 || !exr_header(read_file(path), path, info, false)) {
+      return false;
+    }
   }
   w = info.w;
   h = info.h;
@@ -889,12 +892,13 @@ inline std::vector<float> read_exr_f32(const fs::path& path, int& w, int& h) {
   for (int b = 0; b < blocks; ++b) {
     uint64_t off;
     memcpy(&off, data.data() + info.tableOffset + (size_t)b * 8, 8);
-    CHECK_MSG(off + 8 <= data.size(), "truncated OpenEXR file: " + path.string());
+    // offsets come from the file: no arithmetic on them before they are known to lie inside it (off + 8 would wrap)
+    CHECK_MSG(data.size() >= 8 && off <= data.size() - 8, "truncated OpenEXR file: " + path.string());
     int32_t y, size;
     memcpy(&y, data.data() + off, 4);
     memcpy(&size, data.data() + off + 4, 4);
+    CHECK_MSG(y >= 0 && y < h && size >= 0 && (size_t)size <= data.size() - 8 - off, "corrupt OpenEXR chunk: " + path.string());
     const int n = std::min(lines, h - y);
-    CHECK_MSG(y >= 0 && y < h && n > 0 && size >= 0 && off + 8 + (size_t)size <= data.size(), "corrupt OpenEXR chunk: " + path.string());
     const size_t raw = (size_t)n * w * 4;
     const unsigned char* src = reinterpret_cast<const unsigned char*>(data.data() + off + 8);
     unsigned char* dst = reinterpret_cast<unsigned char*>(out.data() + (size_t)y * w);
@@ -1142,14 +1146,20 @@ struct IoPool {
       });
     }
   }
-  void submit(std::function<void()> job) {
+  // urgent: ahead of everything queued (the staging copies the GPU-feeding thread waits for must not sit behind a
+  // second's worth of file writes)
+  void submit(std::function<void()> job, bool urgent = false) {
     if (workers.empty()) {
       job();
       return;
     }
     {
       std::lock_guard<std::mutex> lk(mu);
-      queue.push_back(std::move(job));
+      if (urgent) {
+        queue.push_front(std::move(job));
+      } else {
+        queue.push_back(std::move(job));
+      }
     }
     cvWork.notify_one();
   }
@@ -1174,7 +1184,7 @@ struct IoBatch {
   std::condition_variable cv;
   int pending = 0;
   std::string error;  // first fatal error of a job; re-raised by wait() on the waiting thread
-  void add(IoPool& pool, std::function<void()> job) {
+  void add(IoPool& pool, std::function<void()> job, bool urgent = false) {
     {
       std::lock_guard<std::mutex> lk(mu);
       ++pending;
@@ -1196,7 +1206,7 @@ struct IoBatch {
       }
       --pending;
       cv.notify_all();
-    });
+    }, urgent);
   }
   bool done() {
     std::lock_guard<std::mutex> lk(mu);

@@ -3,6 +3,7 @@
 // HIP context, and the I/O pipeline around the GPU (worker-pool PNG / PFM decode into page-locked staging
 // memory, uploads, downloads into page-locked memory, worker-pool file writes).
 #pragma once
+#include <deque>
 #include "cli_common.h"
 
 namespace cli {
@@ -394,6 +395,11 @@ struct FrameStore {
       CHECK_MSG(p != nullptr || count == 0, "out of host memory");
       n = count;
     }
+    void release() {
+      free(p);
+      p = nullptr;
+      n = 0;
+    }
     T* data() const { return p; }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
@@ -406,6 +412,15 @@ struct FrameStore {
   };
   std::vector<std::vector<Level>> data;  // [frame index][level]
   double waited = 0;
+  // Decodes are started in the order the level loop consumes them (schedule / pump), and only while the host
+  // memory of the started-but-not-yet-handed-over (frame, level) buffers stays under `budget`: with the frames
+  // resident in HBM a buffer is freed as soon as its level is handed over, so a chunk of any length needs a
+  // bounded amount of host memory (round 3 decoded every level of every frame up front and kept all of it).
+  // Out of core the library streams from these buffers whenever it needs a level: they stay, nothing is throttled.
+  std::deque<std::pair<int, int>> pending;  // (frame index, level), consumption order
+  std::vector<std::vector<char>> started;   // [frame index][level]
+  size_t inFlight = 0, budget = (size_t)8 << 30;
+  bool throttle = true;
 
   FrameStore(const DerpJob& job, IoPool& p, const std::vector<int>& owned) : J(job), pool(p), frames(owned) {
     inTop = J.levelStart < J.numLevels - 1 ? J.levelStart + 1 : J.levelStart;
@@ -415,6 +430,30 @@ struct FrameStore {
       for (auto& l : f) {
         l.batch.reset(new IoBatch);
       }
+    }
+    started.assign(frames.size(), std::vector<char>(J.numLevels, 0));
+    if (const char* e = getenv("DERP_DECODE_BUDGET_GB")) {
+      budget = (size_t)(atof(e) * (double)((size_t)1 << 30));
+    }
+  }
+  size_t level_bytes(int level) const {
+    const size_t n = J.npx(level);
+    const bool compute = level <= J.levelStart;
+    return (compute ? n * 6 * J.S : 0) + (J.useFg ? n * J.S + (compute ? n * 4 * J.D : 0) : 0) + (compute ? 0 : n * 4 * J.D);
+  }
+  void schedule(int k, int level) { pending.emplace_back(k, level); }
+  // start queued decodes while they fit the budget (one is always allowed: progress)
+  void pump() {
+    while (!pending.empty()) {
+      const auto kl = pending.front();
+      const size_t b = level_bytes(kl.second);
+      if (throttle && inFlight > 0 && inFlight + b > budget) {
+        break;
+      }
+      pending.pop_front();
+      inFlight += b;
+      started[kl.first][kl.second] = 1;
+      start_decode(kl.first, kl.second);
     }
   }
   ~FrameStore() {
@@ -493,6 +532,14 @@ struct FrameStore {
 
   void wait(int k, int level) {
     Timer t;
+    while (!started[k][level]) {  // not started for lack of budget: the consumer is here, so it goes now
+      CHECK_MSG(!pending.empty(), "frame level was never scheduled for decoding");
+      const auto kl = pending.front();
+      pending.pop_front();
+      inFlight += level_bytes(kl.second);
+      started[kl.first][kl.second] = 1;
+      start_decode(kl.first, kl.second);
+    }
     data[k][level].batch->wait();
     waited += t.s();
   }
@@ -517,7 +564,7 @@ struct FrameStore {
         A.ensure(plane * sizeof(uint16_t));
         void* dst = A.p;
         const uint16_t* src = L.color.data() + plane * s;
-        bounceReady[s % kBounce].add(pool, [=] { memcpy(dst, src, plane * sizeof(uint16_t)); });
+        bounceReady[s % kBounce].add(pool, [=] { memcpy(dst, src, plane * sizeof(uint16_t)); }, true);
       };
       for (int s = 0; s < std::min(kBounce, J.S); ++s) {
         stage(s);
@@ -538,6 +585,14 @@ struct FrameStore {
       for (int d = 0; d < J.D; ++d) {
         DERP_OK(ctx, derp_seq_upload_disparity(seq, frames[k], level, d, L.prev.data() + J.npx(level) * d));
       }
+    }
+    if (resident) {  // every byte is in HBM (the calls above return after their copies): give the host memory back
+      L.color.release();
+      L.mask.release();
+      L.bg.release();
+      L.prev.release();
+      inFlight -= std::min(inFlight, level_bytes(level));
+      pump();
     }
   }
 };
@@ -592,8 +647,10 @@ struct LevelWriter {
     }
   }
   // a sequence frame's level (resident slot or out-of-core host store) instead of the selected frame's
+  // fromScratch: the frame was filtered ahead of the level's Transfer (derp_seq_level_filter_frame); its filtered
+  // level comes from the filter's scratch over the copy stream while the following frames compute
   void save_seq(derp_seq* seq, int frame, int parity, size_t offset, int level, const std::string& frameName,
-                const std::vector<fs::path>& dirs, bool pngToo) {
+                const std::vector<fs::path>& dirs, bool pngToo, bool fromScratch = false) {
     derp_ctx* ctx = J.ctx;
     const int w = J.W[level], h = J.H[level];
     const bool png = J.savePng && pngToo, exr = J.saveExr && pngToo;
@@ -601,7 +658,11 @@ struct LevelWriter {
       float* disp = reinterpret_cast<float*>(static_cast<char*>(arena[parity].p) + offset) + J.npx(level) * d;
       {
         Timer t;
-        DERP_OK(ctx, derp_seq_download_disparity(seq, frame, level, d, disp));
+        if (fromScratch) {
+          DERP_OK(ctx, derp_seq_download_filtered(seq, frame, level, d, disp));
+        } else {
+          DERP_OK(ctx, derp_seq_download_disparity(seq, frame, level, d, disp));
+        }
         downloading += t.s();
       }
       std::vector<fs::path> bases;

@@ -190,7 +190,11 @@ __device__ __forceinline__ double atan2_ypos_lut(double y, double x, const doubl
 // (1 = interval constants from scalar literals, 2 = from the table `atanLut` in LDS).
 template <int LEAN = 0>
 DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = nullptr) {
+#ifdef DERP_MIX_HOT_ONLY
+  if (DERP_MIX_HOT_ONLY || c.type == DERP_FTHETA) {
+#else
   if (c.type == DERP_FTHETA) {
+#endif
     const double xy = sqrt(p.x * p.x + p.y * p.y);
 #if defined(__HIP_DEVICE_COMPILE__)
     if (LEAN) {

@@ -123,6 +123,7 @@ struct derp_ctx {
   int cur = -1;
   int DB = 0;  // dst batch that fits the table budget
   DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask, pairCount;
+  DevBuf temporalCarry;  // accumulators of a temporal window longer than one launch holds
   DevBuf projWarp, projColor, projBias, projWarpInv, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
   DevBuf rayDir, behind;  // per destination pixel: ray direction [3][D][n] f64, sources facing away [D][n] (k_pixel_rays)
   int warpCachedLevel = -1;
@@ -930,6 +931,38 @@ int select_frame(derp_ctx* c, int slot) {
   return 0;
 }
 
+// temporalJointBilateralFilter (TemporalBilateralFilter.h:126-215) of `planes` planes over a window of n frames,
+// frame `centre` being the one filtered: one launch per kMaxTemporalFrames frames, the sums carried between them
+int temporal_launch(derp_ctx* c, const void* const* guides, const float* const* images, const uint8_t* const* masks, int n,
+                    int centre, int W, int H, int planes, float sigma, int radius, float w0, float w1, float w2,
+                    float* out, const int* dst2src) {
+  if (n < 1 || centre < 0 || centre >= n) {
+    return fail(c, "temporal window must hold at least the centre frame");
+  }
+  if (n > kMaxTemporalFrames) {
+    ALLOC(c, c->temporalCarry, (size_t)planes * W * H * sizeof(float2));
+  }
+  for (int t0 = 0; t0 < n; t0 += kMaxTemporalFrames) {
+    TemporalFrames F;
+    F.n = std::min(kMaxTemporalFrames, n - t0);
+    for (int t = 0; t < F.n; ++t) {
+      F.guides[t] = reinterpret_cast<const ushort4*>(guides[t0 + t]);
+      F.images[t] = images[t0 + t];
+      F.masks[t] = masks[t0 + t];
+    }
+    F.refGuide = reinterpret_cast<const ushort4*>(guides[centre]);
+    F.refImage = images[centre];
+    F.refMask = masks[centre];
+    F.carry = n > kMaxTemporalFrames ? c->temporalCarry.as<float2>() : nullptr;
+    F.first = t0 == 0;
+    F.last = t0 + F.n >= n;
+    hipLaunchKernelGGL(k_temporal, grid2d(W, H, planes, kBlk2d), kBlk2d, 0, c->stream, F, W, H, sigma, radius, w0, w1, w2,
+                       out, dst2src);
+    KCHECK(c);
+  }
+  return 0;
+}
+
 }  // namespace
 
 // =========================================================================================
@@ -1066,7 +1099,7 @@ void derp_destroy(derp_ctx* c) {
   c->devMask.release();
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
                     &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
-                    &c->projWarp, &c->projColor, &c->projBias, &c->projWarpInv, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
+                    &c->projWarp, &c->projColor, &c->projBias, &c->projWarpInv, &c->temporalCarry, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
   }
@@ -2098,37 +2131,31 @@ int derp_masked_median(derp_ctx* c, const float* image, const float* background,
 int derp_temporal_filter_dev(derp_ctx* c, const void* const* guides, const float* const* disps,
                              const uint8_t* const* masks, int n_frames, int w, int h, int frame_offset, float sigma,
                              int space_radius, float w0, float w1, float w2, float* out_dev) {
-  if (!c || n_frames < 1 || n_frames > kMaxTemporalFrames || frame_offset < 0 || frame_offset >= n_frames) {
-    return fail(c, "temporal window must hold 1..%d frames and contain the centre frame", kMaxTemporalFrames);
+  if (!c || n_frames < 1 || frame_offset < 0 || frame_offset >= n_frames) {
+    return fail(c, "temporal window must hold at least one frame and contain the centre frame");
   }
   HIPCHK(c, hipSetDevice(c->device));
-  TemporalFrames F;
-  F.n = n_frames;
-  for (int t = 0; t < n_frames; ++t) {
-    F.guides[t] = reinterpret_cast<const ushort4*>(guides[t]);
-    F.images[t] = disps[t];
-    F.masks[t] = masks[t];
-  }
-  hipLaunchKernelGGL(k_temporal, grid2d(w, h, 1, kBlk2d), kBlk2d, 0, c->stream, F, w, h, frame_offset, sigma,
-                     space_radius, w0, w1, w2, out_dev, (const int*)nullptr);
-  KCHECK(c);
-  return 0;
+  return temporal_launch(c, guides, disps, masks, n_frames, frame_offset, w, h, 1, sigma, space_radius, w0, w1, w2, out_dev,
+                         nullptr);
 }
 
 int derp_temporal_filter(derp_ctx* c, const uint16_t* const* guides, const float* const* disps,
                          const uint8_t* const* masks, int n_frames, int w, int h, int frame_offset, float sigma,
                          int space_radius, float w0, float w1, float w2, float* out) {
-  if (!c || n_frames < 1 || n_frames > kMaxTemporalFrames) {
-    return fail(c, "temporal window must hold 1..%d frames", kMaxTemporalFrames);
+  if (!c || n_frames < 1) {
+    return fail(c, "temporal window must hold at least one frame");
   }
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = (size_t)w * h;
   std::vector<DevBuf> g4(n_frames), im(n_frames), m(n_frames);
   DevBuf g3, res;
   int rc = 0;
-  const void* gp[kMaxTemporalFrames];
-  const float* ip[kMaxTemporalFrames];
-  const uint8_t* mp[kMaxTemporalFrames];
+  std::vector<const void*> gpv(n_frames);
+  std::vector<const float*> ipv(n_frames);
+  std::vector<const uint8_t*> mpv(n_frames);
+  const void** gp = gpv.data();
+  const float** ip = ipv.data();
+  const uint8_t** mp = mpv.data();
   do {
     if (g3.ensure(n * 6) || res.ensure(n * 4)) {
       rc = fail(c, "out of device memory");

@@ -54,6 +54,12 @@ namespace derp {
 #ifndef DERP_ATAN_LUT
 #define DERP_ATAN_LUT 1
 #endif
+// tools/valu_model.py only (never a product build): compile the cost kernels without their cold paths — the
+// tap-by-tap SSD fallback and the non-FTHETA camera types — so that the static instruction mix it weights the
+// typed VALU counters with is the mix of the hot loops
+#ifndef DERP_MIX_HOT_ONLY
+#define DERP_MIX_HOT_ONLY 0
+#endif
 // computeSSD's 4x4-block arithmetic in plain fp32 (1) or packed fp32 (0), per kernel family
 #ifndef DERP_RANDOM_SSD_SCALAR
 #define DERP_RANDOM_SSD_SCALAR 1
@@ -442,6 +448,8 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     } else {
       block_packed((v2f){xw[0], xw[2]}, xw[1], yw);
     }
+  } else if (DERP_MIX_HOT_ONLY) {
+    first = second = 0.f;
   } else {
     // float rounding of x + dx crossed a .5 boundary: taps no longer form a 4x4 block
     for (int ix = 0; ix < 3; ++ix) {
@@ -2132,16 +2140,26 @@ __global__ void k_bgrx_to_bgr(const ushort4* __restrict__ in, uint16_t* __restri
 // temporal joint bilateral — TemporalBilateralFilter.h:126-172 (quirks kept: accumulates the
 // CENTRE pixel of frame t, int colour difference / 65535.f, no sumWeight == 0 guard)
 // ----------------------------------------------------------------------------------------
-constexpr int kMaxTemporalFrames = 31;  // window of 2 * time_radius + 1 frames, time_radius <= 15
+constexpr int kMaxTemporalFrames = 31;  // frames one launch walks; longer windows run as several launches (carry)
 struct TemporalFrames {
   const ushort4* guides[kMaxTemporalFrames];  // per frame: colour planes [S or 1][H*W]
   const float* images[kMaxTemporalFrames];    // per frame: disparity planes [D][H*W]
   const uint8_t* masks[kMaxTemporalFrames];   // per frame: fov & fg planes [D][H*W]
   int n;
+  // the frame being filtered (TemporalBilateralFilter.h:140-147: its guide is the reference colour, its mask gates
+  // the pixel, its disparity passes through where the mask is 0)
+  const ushort4* refGuide;
+  const float* refImage;
+  const uint8_t* refMask;
+  // a window longer than kMaxTemporalFrames (--time_radius has no limit in the reference,
+  // TemporalBilateralFilter.cpp:55,108-109) is walked by consecutive launches over consecutive chunks of frames; the
+  // two float accumulators travel through `carry` [planes][H*W], so the sums see the same additions in the same order
+  float2* carry;
+  int first, last;  // chunk flags: first = start the sums at 0, last = divide and write `out`
 };
 // blockIdx.z = destination camera d: disparity / mask plane d, colour plane dst2src[d] (plane 0 when
 // dst2src is null: the single-camera entry point)
-__global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, float sigma, int radius, float weight0,
+__global__ void k_temporal(TemporalFrames F, int W, int H, float sigma, int radius, float weight0,
                            float weight1, float weight2, float* __restrict__ out, const int* __restrict__ dst2src) {
   __shared__ unsigned long long expTab[32];
   {
@@ -2158,14 +2176,21 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
   const size_t n = (size_t)W * H;
   const size_t pd = (size_t)blockIdx.z * n, pg = dst2src ? (size_t)dst2src[blockIdx.z] * n : 0;
   const size_t idx = (size_t)y * W + x;
-  if (!F.masks[frameOffset][pd + idx]) {
-    out[pd + idx] = F.images[frameOffset][pd + idx];
+  if (!F.refMask[pd + idx]) {
+    if (F.last) {
+      out[pd + idx] = F.refImage[pd + idx];
+    }
     return;
   }
-  const ushort4 ref = F.guides[frameOffset][pg + idx];
+  const ushort4 ref = F.refGuide[pg + idx];
   const float sig2 = sigma * sigma;
   const double rcpSig2 = 1.0 / (double)sig2;
   float weightedSumPix = 0.f, sumWeight = 0.f;
+  if (!F.first) {
+    const float2 acc = F.carry[pd + idx];
+    weightedSumPix = acc.x;
+    sumWeight = acc.y;
+  }
   for (int t = 0; t < F.n; ++t) {
     const float centre = F.images[t][pd + idx];
     const uint8_t* __restrict__ mask = F.masks[t] + pd;
@@ -2189,7 +2214,11 @@ __global__ void k_temporal(TemporalFrames F, int W, int H, int frameOffset, floa
       }
     }
   }
-  out[pd + idx] = weightedSumPix / sumWeight;
+  if (F.last) {
+    out[pd + idx] = weightedSumPix / sumWeight;
+  } else {
+    F.carry[pd + idx] = make_float2(weightedSumPix, sumWeight);
+  }
 }
 
 // ----------------------------------------------------------------------------------------

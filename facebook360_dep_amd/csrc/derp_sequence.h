@@ -152,6 +152,9 @@ struct derp_seq {
   int levelReady = -1;                          // level whose compute finished and whose filter has not run yet
   int levelExchanged = -1;                      // level whose halo disparities have arrived (exchange ran / was marked)
   int computeLevel = -1, computedFrames = 0;    // progress of derp_seq_level_compute_frame over the owned frames
+  std::vector<int> computedAt, filteredAt;      // [owned index]: the level whose raw result / filtered scratch the frame holds
+  std::vector<hipEvent_t> filteredEv;           // [owned index]: recorded behind the frame's filter kernel
+  int fovLevel = -1;                            // level q->fov was built for
   // ---- out-of-core mode (resident_frames < owned frames)
   bool streaming = false;
   int nSlots = 0;
@@ -451,8 +454,8 @@ int derp_seq_create(derp_seq** out, derp_ctx* c, int first, int last, int rank, 
     derp_seq_destroy(q);
     return rc;
   };
-  if (q->opt.time_radius < 0 || 2 * q->opt.time_radius + 1 > kMaxTemporalFrames) {
-    return bail(fail(c, "time_radius %d out of range (0..%d)", q->opt.time_radius, (kMaxTemporalFrames - 1) / 2));
+  if (q->opt.time_radius < 0) {
+    return bail(fail(c, "time_radius %d is negative", q->opt.time_radius));
   }
   if (!q->opt.do_temporal_filter) {
     q->opt.time_radius = 0;  // no window, no halo, no exchange: replicas
@@ -500,6 +503,14 @@ int derp_seq_create(derp_seq** out, derp_ctx* c, int first, int last, int rank, 
     }
   }
   q->filtered.resize(q->streaming ? 1 : q->owned.size());  // out of core: one frame is filtered, then streamed out
+  q->computedAt.assign(q->owned.size(), -1);
+  q->filteredAt.assign(q->owned.size(), -1);
+  q->filteredEv.assign(q->streaming ? 0 : q->owned.size(), nullptr);
+  for (auto& e : q->filteredEv) {
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+      return bail(fail(c, "hipEventCreate failed"));
+    }
+  }
   for (auto& b : q->filtered) {
     if (b.ensure(nmax * c->D * sizeof(float))) {
       return bail(fail(c, "out of device memory allocating the filtered level"));
@@ -574,6 +585,11 @@ void derp_seq_destroy(derp_seq* q) {
   }
   for (auto& b : q->filtered) {
     b.release();
+  }
+  for (auto& e : q->filteredEv) {
+    if (e) {
+      (void)hipEventDestroy(e);
+    }
   }
   q->fov.release();
   q->winMask.release();
@@ -881,8 +897,9 @@ int stream_filter_level(derp_seq* q, int level, int W, int H, int radius) {
     const int t = q->owned[j];
     int lo, hi;
     seq_window(t, q->first, q->last, q->opt.time_radius, &lo, &hi);
-    TemporalFrames F;
-    F.n = hi - lo + 1;
+    std::vector<const void*> wg(hi - lo + 1);
+    std::vector<const float*> wi(hi - lo + 1);
+    std::vector<const uint8_t*> wmk(hi - lo + 1);
     for (int u = lo; u <= hi; ++u) {
       const void *pc, *pd, *pm;
       const int ku = owned_index(q, u);
@@ -925,14 +942,12 @@ int stream_filter_level(derp_seq* q, int level, int W, int H, int radius) {
       } else {
         pm = q->fov.p;
       }
-      F.guides[u - lo] = reinterpret_cast<const ushort4*>(pc);
-      F.images[u - lo] = reinterpret_cast<const float*>(pd);
-      F.masks[u - lo] = reinterpret_cast<const uint8_t*>(pm);
+      wg[u - lo] = pc;
+      wi[u - lo] = reinterpret_cast<const float*>(pd);
+      wmk[u - lo] = reinterpret_cast<const uint8_t*>(pm);
     }
-    hipLaunchKernelGGL(k_temporal, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, F, W, H, t - lo, q->opt.sigma,
-                       radius, q->opt.weight_b, q->opt.weight_g, q->opt.weight_b, q->filtered[0].as<float>(),
-                       c->dst2src.as<int>());
-    KCHECK(c);
+    TRY(temporal_launch(c, wg.data(), wi.data(), wmk.data(), hi - lo + 1, t - lo, W, H, c->D, q->opt.sigma, radius,
+                        q->opt.weight_b, q->opt.weight_g, q->opt.weight_b, q->filtered[0].as<float>(), c->dst2src.as<int>()));
     // "Transfer": the filtered level is the frame's result; the raw levels stay untouched in hostRaw
     HIPCHK(c, hipMemcpyAsync(q->hostDisp[j][level], q->filtered[0].p, n * c->D * sizeof(float), hipMemcpyDeviceToHost,
                              c->stream));
@@ -1111,6 +1126,8 @@ int derp_seq_level_compute_frame(derp_seq* q, int level, int frame) {
   }
   c->opt.rebuild_warp_tables = rebuild;
   TRY(rc);
+  q->computedAt[k] = level;
+  q->filteredAt[k] = -1;
   if (++q->computedFrames >= (int)q->owned.size()) {
     q->levelReady = level;
   }
@@ -1158,6 +1175,118 @@ int derp_seq_mark_exchanged(derp_seq* q, int level) {
   return 0;
 }
 
+namespace {
+// q->fov = the destinations' FOV masks at this level (generateFovMasks), built once per level
+int seq_fov_masks(derp_seq* q, int level) {
+  derp_ctx* c = q->c;
+  if (q->fovLevel != level) {
+    const int W = c->LW[level], H = c->LH[level];
+    hipLaunchKernelGGL(k_fov_mask, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), W, H,
+                       q->fov.as<uint8_t>());
+    KCHECK(c);
+    q->fovLevel = level;
+  }
+  return 0;
+}
+// temporalJointBilateralFilter of owned frame k over its window into q->filtered[k] (resident mode)
+int seq_filter_frame(derp_seq* q, int level, int k) {
+  derp_ctx* c = q->c;
+  const int W = c->LW[level], H = c->LH[level];
+  const size_t n = (size_t)W * H;
+  const int radius = temporal_space_radius(q, level);
+  const int t = q->owned[k];
+  int lo, hi;
+  seq_window(t, q->first, q->last, q->opt.time_radius, &lo, &hi);
+  std::vector<const void*> wg(hi - lo + 1);
+  std::vector<const float*> wi(hi - lo + 1);
+  std::vector<const uint8_t*> wmk(hi - lo + 1);
+  for (int u = lo; u <= hi; ++u) {
+    void *pc, *pd, *pm;
+    size_t b;
+    TRY(seq_buffer(q, u, level, 0, &pc, &b));
+    TRY(seq_buffer(q, u, level, 2, &pd, &b));
+    if (q->opt.use_foreground_masks) {  // mask = fg & fov of each frame (TemporalBilateralFilter.cpp:150-160)
+      TRY(seq_buffer(q, u, level, 1, &pm, &b));
+      uint8_t* wm = q->winMask.as<uint8_t>() + (size_t)(u - lo) * n * c->D;
+      hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), c->D), dim3(256), 0, c->stream, q->fov.as<uint8_t>(),
+                         (const uint8_t*)pm, c->dst2src.as<int>(), 0, n, wm);
+      KCHECK(c);
+      pm = wm;
+    } else {
+      pm = q->fov.p;  // generateAllPassMasks & fov
+    }
+    wg[u - lo] = pc;
+    wi[u - lo] = reinterpret_cast<const float*>(pd);
+    wmk[u - lo] = reinterpret_cast<const uint8_t*>(pm);
+  }
+  // weights (b, g, b): the reference passes FLAGS_weight_b for the third channel (TemporalBilateralFilter.cpp:176-178)
+  TRY(temporal_launch(c, wg.data(), wi.data(), wmk.data(), hi - lo + 1, t - lo, W, H, c->D, q->opt.sigma, radius,
+                      q->opt.weight_b, q->opt.weight_g, q->opt.weight_b, q->filtered[k].as<float>(), c->dst2src.as<int>()));
+  q->filteredAt[k] = level;
+  HIPCHK(c, hipEventRecord(q->filteredEv[k], c->stream));
+  return 0;
+}
+}  // namespace
+
+// One owned frame's filter AHEAD of derp_seq_level_filter — as soon as every frame of its window holds its raw
+// level (owned frames: computed at this level; halo frames: exchanged), which for the frames in the middle of a
+// rank's chunk is long before the last frame of the level is computed. The result waits in the frame's scratch
+// (derp_seq_download_filtered) — nothing is overwritten: the Transfer still happens in derp_seq_level_filter, after
+// every frame is filtered. Returns 0 = filtered, 2 = not yet possible (no error recorded), 1 = error.
+int derp_seq_level_filter_frame(derp_seq* q, int level, int frame) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  HIPCHK(c, hipSetDevice(c->device));
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0) {
+    return fail(c, "frame %d is not owned by rank %d", frame, q->rank);
+  }
+  if (!q->opt.do_temporal_filter || q->streaming) {
+    return 2;
+  }
+  if (q->filteredAt[k] == level) {
+    return 0;
+  }
+  int lo, hi;
+  seq_window(frame, q->first, q->last, q->opt.time_radius, &lo, &hi);
+  for (int u = lo; u <= hi; ++u) {
+    const int ku = owned_index(q, u);
+    if (ku >= 0 ? q->computedAt[ku] != level : q->levelExchanged != level) {
+      return 2;
+    }
+  }
+  Span sp(c, ST_TEMPORAL, level);
+  TRY(seq_fov_masks(q, level));
+  return seq_filter_frame(q, level, k);
+}
+
+// A destination's filtered level of an owned frame straight from the filter's scratch, on the library's copy
+// stream behind the frame's filter kernel: the compute stream keeps running the frames that follow.
+int derp_seq_download_filtered(derp_seq* q, int frame, int level, int d, float* out) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0 || d < 0 || d >= c->D || !out) {
+    return fail(c, "bad frame / destination index / null output");
+  }
+  if (q->streaming || q->filteredAt[k] != level) {
+    return fail(c, "frame %d has no filtered level %d in its scratch (derp_seq_level_filter_frame)", frame, level);
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n = npx(c, level);
+  HIPCHK(c, hipStreamWaitEvent(c->copyStream, q->filteredEv[k], 0));
+  HIPCHK(c, hipMemcpyAsync(out, q->filtered[k].as<float>() + (size_t)d * n, n * sizeof(float), hipMemcpyDeviceToHost,
+                           c->copyStream));
+  HIPCHK(c, hipStreamSynchronize(c->copyStream));
+  return 0;
+}
+
 int derp_seq_level_filter(derp_seq* q, int level) {
   if (!q) {
     return 1;
@@ -1179,51 +1308,24 @@ int derp_seq_level_filter(derp_seq* q, int level) {
   const int W = c->LW[level], H = c->LH[level];
   const size_t n = (size_t)W * H;
   Span sp(c, ST_TEMPORAL, level);  // masks + temporal kernels + write-back of every owned frame
-  hipLaunchKernelGGL(k_fov_mask, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, c->camsDst.as<Cam>(), W, H,
-                     q->fov.as<uint8_t>());
-  KCHECK(c);
-  const int radius = temporal_space_radius(q, level);
+  TRY(seq_fov_masks(q, level));
   if (q->streaming) {
+    const int radius = temporal_space_radius(q, level);
     TRY(stream_filter_level(q, level, W, H, radius));
     q->levelReady = -1;
     return 0;
   }
   for (int k = 0; k < (int)q->owned.size(); ++k) {
-    const int t = q->owned[k];
-    int lo, hi;
-    seq_window(t, q->first, q->last, q->opt.time_radius, &lo, &hi);
-    TemporalFrames F;
-    F.n = hi - lo + 1;
-    for (int u = lo; u <= hi; ++u) {
-      void *pc, *pd, *pm;
-      size_t b;
-      TRY(seq_buffer(q, u, level, 0, &pc, &b));
-      TRY(seq_buffer(q, u, level, 2, &pd, &b));
-      if (q->opt.use_foreground_masks) {  // mask = fg & fov of each frame (TemporalBilateralFilter.cpp:150-160)
-        TRY(seq_buffer(q, u, level, 1, &pm, &b));
-        uint8_t* wm = q->winMask.as<uint8_t>() + (size_t)(u - lo) * n * c->D;
-        hipLaunchKernelGGL(k_and_masks, dim3(flat_grid(n), c->D), dim3(256), 0, c->stream, q->fov.as<uint8_t>(),
-                           (const uint8_t*)pm, c->dst2src.as<int>(), 0, n, wm);
-        KCHECK(c);
-        pm = wm;
-      } else {
-        pm = q->fov.p;  // generateAllPassMasks & fov
-      }
-      F.guides[u - lo] = reinterpret_cast<const ushort4*>(pc);
-      F.images[u - lo] = reinterpret_cast<const float*>(pd);
-      F.masks[u - lo] = reinterpret_cast<const uint8_t*>(pm);
+    if (q->filteredAt[k] != level) {  // not filtered ahead of time by derp_seq_level_filter_frame
+      TRY(seq_filter_frame(q, level, k));
     }
-    // weights (b, g, b): the reference passes FLAGS_weight_b for the third channel (TemporalBilateralFilter.cpp:176-178)
-    hipLaunchKernelGGL(k_temporal, grid2d(W, H, c->D, kBlk2d), kBlk2d, 0, c->stream, F, W, H, t - lo, q->opt.sigma,
-                       radius, q->opt.weight_b, q->opt.weight_g, q->opt.weight_b, q->filtered[k].as<float>(),
-                       c->dst2src.as<int>());
-    KCHECK(c);
   }
   // "Transfer" (pipeline.py:397-408): every owned frame is filtered before any raw level is overwritten
   for (int k = 0; k < (int)q->owned.size(); ++k) {
     SlotView v = slot_view(c, k);
     HIPCHK(c, hipMemcpyAsync((*v.disp)[level].p, q->filtered[k].p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice,
                              c->stream));
+    q->computedAt[k] = -1;  // the slot holds the filtered level now: no window may read it as a raw level
   }
   q->levelReady = -1;
   return 0;

@@ -382,6 +382,22 @@ class SequenceRunner:
     def filter(self, level):
         self._ck(derp.lib().derp_seq_level_filter(self.h, level))
 
+    def filter_frame(self, level, frame):
+        """One owned frame ahead of `filter` -> True if it could be filtered now (its window is complete)."""
+        rc = derp.lib().derp_seq_level_filter_frame(self.h, level, frame)
+        if rc == 2:
+            return False
+        self._ck(rc)
+        return True
+
+    def download_filtered(self, frame, level, d):
+        import numpy as np
+
+        w, h = self.g.sizes[level]
+        out = np.zeros((h, w), dtype=np.float32)
+        self._ck(derp.lib().derp_seq_download_filtered(self.h, frame, level, d, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def before_exchange(self):
         self.g.synchronize()  # the level's kernels ran on the library's stream
 

@@ -328,6 +328,14 @@ int derp_seq_mark_exchanged(derp_seq* seq, int level);     /* external transport
 int derp_seq_level_filter(derp_seq* seq, int level);       /* temporal filter of every owned frame + Transfer; fails
                                                             * unless compute (and, with halo frames, the exchange) of
                                                             * this level completed first */
+/* One owned frame's filter AHEAD of derp_seq_level_filter: possible as soon as every frame of its window holds the
+ * level's raw result (owned frames computed, halo frames exchanged) — for the frames in the middle of a chunk long
+ * before the level's last frame is computed, so that their files can be written behind the remaining compute
+ * (TemporalBilateralFilter.cpp:139-184 per frame). The result stays in the frame's scratch; the Transfer is still
+ * derp_seq_level_filter's. Returns 0 = filtered, 2 = not possible yet / out of core / filter off (no error), 1 = error. */
+int derp_seq_level_filter_frame(derp_seq* seq, int level, int frame);
+/* ... and its download from that scratch, on the copy stream (the compute stream keeps running) */
+int derp_seq_download_filtered(derp_seq* seq, int frame, int level, int dst, float* disparity);
 int derp_seq_run(derp_seq* seq, int level_start, int level_end);
 int derp_seq_stats(derp_seq* seq, uint64_t* bytes_sent, uint64_t* bytes_received, double* exchange_ms);
 int derp_seq_stats_reset(derp_seq* seq);

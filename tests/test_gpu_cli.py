@@ -29,8 +29,8 @@ def dataset(built, tmp_path_factory):
     return dict(root=root, rig=rig, sizes=sizes, res=res, n=n, frames=frames)
 
 
-def run(binary, *flags, expect_ok=True, env=None):
-    p = subprocess.run([os.path.join(BIN, binary)] + list(flags), capture_output=True, text=True, timeout=600, env=env)
+def run(binary, *flags, expect_ok=True, env=None, timeout=600):
+    p = subprocess.run([os.path.join(BIN, binary)] + list(flags), capture_output=True, text=True, timeout=timeout, env=env)
     if expect_ok:
         assert p.returncode == 0, p.stderr[-3000:]
     return p
@@ -300,7 +300,20 @@ def test_derp_sequence_two_processes_exchange_through_files(dataset, tmp_path):
     for name, extra, expect in (("files", ["--exchange=files"], "halo exchange through files"),
                                 ("fallback", [], "RCCL transport unavailable")):
         out = str(tmp_path / name)
-        p = run("DerpSequence", *flags, "--output_root=" + out, "--gpus=2", *extra, env=env)
+        # what a job that crashed on this --output_root would have left behind: a rendezvous token with its go file
+        # and halo files under the names this run will wait for — the start-up rendezvous must wipe them, not read them
+        stale = os.path.join(out, ".derp_seq")
+        os.makedirs(os.path.join(stale, "halo"))
+        with open(os.path.join(stale, "token"), "w") as f:
+            f.write("dead-job")
+        with open(os.path.join(stale, "go.dead-job"), "w") as f:
+            f.write("whatever\n")
+        for level in range(n_levels):
+            for kind in (0, 2):
+                for frame, to in ((1, 1), (2, 0)):
+                    with open(os.path.join(stale, "halo", "L%d_k%d_f%06d_to%d.bin" % (level, kind, frame, to)), "wb") as f:
+                        f.write(b"\0" * (1 << 16))
+        p = run("DerpSequence", *flags, "--output_root=" + out, "--gpus=2", *extra, env=env, timeout=150)
         assert expect in p.stderr and "2 frame(s) owned, 1 halo frame(s)" in p.stderr and \
             "1 frame(s) owned, 2 halo frame(s)" in p.stderr, p.stderr[-3000:]
         for kind in ("disparity_levels", "disparity_time_filtered_levels"):
@@ -309,7 +322,7 @@ def test_derp_sequence_two_processes_exchange_through_files(dataset, tmp_path):
                     for f in range(3):
                         rel = os.path.join(kind, "level_%d" % level, cam, "%06d.pfm" % f)
                         assert open(os.path.join(out, rel), "rb").read() == open(os.path.join(one, rel), "rb").read(), (name, rel)
-        assert not [d for d in os.listdir(out) if d.startswith(".halo")]
+        assert not [d for d in os.listdir(out) if d.startswith(".halo") or d.startswith(".derp_seq")]
 
 
 def test_derp_sequence_failing_rank_takes_the_job_down(dataset, tmp_path):

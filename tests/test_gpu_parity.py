@@ -305,6 +305,26 @@ def test_temporal_filter(small, gpu):
         assert bad == 0, (off, cnt, bad, rel)
 
 
+def test_temporal_filter_window_longer_than_one_launch(small, gpu):
+    """--time_radius has no upper limit in the reference (TemporalBilateralFilter.cpp:55,108-109). One launch of the
+    filter kernel walks 31 frames; longer windows run as consecutive launches that carry the two float sums, i.e. the
+    same additions in the same order: 70 frames (radius 34 + 1 clamped side: three launches) and 32 frames (the first
+    window one launch cannot hold), the filtered frame in the first, a middle and the last chunk — bit for bit."""
+    from oracle import oracle_lib as O
+
+    rng = np.random.default_rng(22)
+    w, h = small["sizes"][2]
+    base = small["frame"]["color"][2][0].astype(np.int64)
+    n = 70
+    guides = [np.clip(base + rng.integers(-300, 300, size=base.shape), 0, 65535).astype(np.uint16) for _ in range(n)]
+    disps = [(1.0 / rng.uniform(0.6, 30.0, size=(h, w))).astype(np.float32) for _ in range(n)]
+    masks = [(rng.random((h, w)) > 0.05).astype(np.uint8) for _ in range(n)]
+    for off, cnt in ((35, 70), (3, 70), (69, 70), (31, 32), (0, 32)):
+        ref = O.temporal_filter(guides[:cnt], disps[:cnt], masks[:cnt], off, 0.01, 1, 0.5, 1.0, 0.5)
+        got = gpu.temporal_filter(guides[:cnt], disps[:cnt], masks[:cnt], off, 0.01, 1, 0.5, 1.0, 0.5)
+        assert _float_equal(got, ref) == 0, (off, cnt)
+
+
 def test_config3_temporal_filter_full_size_properties(built):
     """BASELINE config 3's filter stage at 2048^2 (one camera, 5 frames of the moving scene) through
     properties of temporalJointBilateralFilter (TemporalBilateralFilter.h:126-172): the weights depend

@@ -375,6 +375,39 @@ def test_sequence_out_of_core_two_ranks_and_no_filter(built):
     g3.close()
 
 
+def test_sequence_frames_filtered_ahead_of_the_level(built):
+    """derp_seq_level_filter_frame: a frame is filtered as soon as its window is computed — before the level's last
+    frame — into its scratch, from where derp_seq_download_filtered reads it over the copy stream; the Transfer still
+    waits for derp_seq_level_filter. Every level of every frame equals the oracle, and the early download equals what
+    the slot holds after the Transfer."""
+    n, res, rig, sizes = _setup("tiny")
+    ref = _oracle_sequence("tiny", FIRST, LAST)
+    g, r = _gpu_runner(rig, sizes, res, FIRST, LAST)
+    early = {}
+    for level in range(len(sizes) - 1, -1, -1):
+        done = 0
+        for t in r.owned:
+            r.compute_frame(level, t)
+            while done < len(r.owned) and r.filter_frame(level, r.owned[done]):
+                early[(r.owned[done], level)] = [r.download_filtered(r.owned[done], level, d) for d in range(n)]
+                done += 1
+            # windows reach 2 frames ahead: frame t - 2 is the newest that can be filtered after frame t's compute
+            assert done == max(0, t - FIRST - 1) or t == LAST
+        assert done == len(r.owned)  # the last frame's compute completes every window (one rank: no halo)
+        r.filter(level)  # nothing left to filter: the Transfer
+    g.synchronize()
+    assert _compare_with_oracle([r], ref, n, sizes) == 0
+    for (t, level), planes in early.items():
+        for d in range(n):
+            assert _bad(planes[d], r.download_disparity(t, level, d)) == 0, (t, level, d)
+    # a frame that is not owned is an error; out of turn (window incomplete) is "not yet", not an error
+    r.compute_frame(0, FIRST)
+    assert r.filter_frame(0, FIRST) is False
+    with pytest.raises(Exception):
+        r.filter_frame(0, LAST + 5)
+    g.close()
+
+
 def test_sequence_phases_out_of_order_are_refused(built):
     """derp_seq_level_filter without the level's compute, or (with halo frames) without its exchange, fails
     instead of filtering stale data."""

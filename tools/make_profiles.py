@@ -51,7 +51,7 @@ if body:
         w.writerow(["(non-derp kernels: torch synthetic-input rendering / copies / RCCL, outside the depth path)",
                     sum(int(r[1]) for r in other), sum(int(r[2]) for r in other), "", "", "", "", ""])
 pm = {}
-for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ISSUE", "SQ_INSTS", "L2"):
+for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_ISSUE", "SQ_INSTS", "L2", "VALU_F32", "VALU_F64"):
     path = os.path.join(src, "%s_pmc_%s.json" % (tag, c))
     if not os.path.exists(path):
         continue
@@ -108,6 +108,50 @@ def kernel_view(kernel):
     return out
 
 
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import valu_model  # noqa: E402
+
+UBENCH = os.path.join(dst, "r04_ubench.jsonl")
+
+
+def max_ms(kernel):
+    """duration of the longest dispatch of `kernel` in the kernel trace (= its level-0 launch)"""
+    for r in keep:
+        if kernel in r[0]:
+            try:
+                return float(r[hdr.index("MaxNs")]) / 1e6
+            except (ValueError, IndexError):
+                return None
+    return None
+
+
+def issue_model(kernel, view):
+    """tools/valu_model.py on the typed VALU counters of the level-0 launch: SIMD issue cycles per launch."""
+    if "VALU_F32" not in pm or "VALU_F64" not in pm or not os.path.exists(UBENCH):
+        return None
+    counts = {}
+    for grp in ("VALU_F32", "VALU_F64"):
+        for k, v in pm[grp].items():
+            if kernel in k:
+                for c, x in v.items():
+                    counts[c.replace("SQ_INSTS_VALU_", "").replace("SQ_INSTS_VALU", "VALU")] = x["max"]
+    if not counts.get("VALU"):
+        return None
+    waves = view.get("waves_per_simd_avg") or 3
+    costs = valu_model.class_costs(UBENCH, waves)
+    m = valu_model.issue_cycles(counts, valu_model.static_mix(kernel), costs)
+    out = {"issue_cycles_per_launch": m["cycles_upper"], "issue_cycles_if_simple_ops_coissue": m["cycles_lower"],
+           "instructions_by_class": m["by_class"], "instructions_by_counter": m["dynamic_by_counter"],
+           "class_cycles_used": costs}
+    ms = max_ms(kernel)
+    if ms:
+        avail = N_SIMD * 2.4e9 * ms * 1e-3
+        out["trace_max_ms"] = ms
+        out["issue_frac_at_2.4GHz"] = round(m["cycles_upper"] / avail, 4)
+        out["issue_frac_if_simple_ops_coissue"] = round(m["cycles_lower"] / avail, 4)
+    return out
+
+
 path = os.path.join(dst, "valu_roofline.json")
 tr = json.load(open(path)) if os.path.exists(path) else {}
 pp = kernel_view("k_ping_pong(")
@@ -123,12 +167,23 @@ entry = {
     "ping_pong_level0_wave_cycle_shares": pp.get("wave_cycle_shares"),
     "ping_pong_level0_hbm_bytes_per_launch": pp.get("hbm_bytes_per_launch"),
     "kernels_level0_launch": {n: kernel_view(n) for n in
-                              ("k_ping_pong(", "k_random_proposals", "k_reproject", "k_blur3_u16", "k_joint_bilateral",
-                               "k_temporal", "k_proj_warp", "k_brute_costs")},
+                              ("k_ping_pong(", "k_random_proposals", "k_reproject_bias", "k_proj_warp_inv", "k_blur3_u16",
+                               "k_joint_bilateral", "k_temporal", "k_proj_warp(", "k_brute_costs")},
     "all_launches_fetch_bytes": {n: 2.0 * 1024.0 * val("FETCH_SIZE", n, "FETCH_SIZE", "sum") for n in
-                                 ("k_ping_pong(", "k_random_proposals", "k_reproject", "k_proj_warp",
+                                 ("k_ping_pong(", "k_random_proposals", "k_reproject_bias", "k_proj_warp_inv", "k_proj_warp(",
                                   "k_joint_bilateral", "k_blur3_u16", "k_masked_median", "k_brute_costs", "k_temporal")},
 }
+for n, view in entry["kernels_level0_launch"].items():
+    im = issue_model(n, view)
+    if im:
+        view["issue_model"] = im
+ppm = entry["kernels_level0_launch"]["k_ping_pong("].get("issue_model")
+if ppm:
+    entry["ping_pong_level0_issue_cycles_per_launch"] = ppm["issue_cycles_per_launch"]
+    entry["ping_pong_level0_issue_cycles_if_simple_ops_coissue"] = ppm["issue_cycles_if_simple_ops_coissue"]
+    entry["ping_pong_level0_class_cycles"] = ppm["class_cycles_used"]
+    entry["issue_model"] = ("tools/valu_model.py: typed VALU counters of the level-0 launch (%s_pmc_VALU_F32/_F64.json) priced at the "
+                            "per-class issue intervals of tools/valu_ubench.hip (r04_ubench.jsonl)" % tag)
 # every derp:: kernel of the PMC run (`bench.py --steps 1`: one step = the whole sequence)
 entry["whole_step_hbm_fetch_bytes"] = 2.0 * 1024.0 * sum(v["FETCH_SIZE"]["sum"] for v in pm.get("FETCH_SIZE", {}).values())
 entry["whole_step_hbm_write_bytes"] = 1024.0 * sum(v["WRITE_SIZE"]["sum"] for v in pm.get("WRITE_SIZE", {}).values())
