@@ -339,6 +339,11 @@ int main(int argc, char** argv) {
                "communicator %.3fs (images decoding since %.3fs)", tHost, tDevice - tHost, total.s() - tDevice, tHost));
   // ---- the level loop (pipeline.py:364-408)
   LevelWriter writer(J, pool);
+  // the page-locked upload bounce planes, once, at the finest level's plane size
+  if (nSlots >= nOwned) {
+    store.reserve_bounce(J.levelEnd);
+  }
+  writer.reserve_ring(3);  // frames in flight between the GPU and the disk
   double tCompute = 0, tUpload = 0;
   const std::vector<fs::path> dirs = so.do_temporal_filter
       ? std::vector<fs::path>{J.dispLevels, fs::path(J.outputRoot) / "disparity_time_filtered_levels"}
@@ -351,9 +356,7 @@ int main(int argc, char** argv) {
   }
   for (int level = J.levelStart; level >= J.levelEnd; --level) {
     LOG_INFO(fmt("Processing level %d of %d frame(s)", level, nOwned));
-    const int parity = level & 1;
-    const size_t frameBytes = J.npx(level) * 4 * J.D;
-    writer.begin(parity, frameBytes * std::max(nOwned, 1));
+    const double lv0 = total.s(), dec0 = store.waited, up0 = tUpload, dl0 = writer.downloading, wr0 = writer.waited;
     // A frame is filtered as soon as its window is computed (derp_seq_level_filter_frame) and its files leave one
     // frame later, from the filter's scratch over the copy stream — behind the compute of the frames that follow,
     // instead of all at once after the level's last frame (at the finest level that was 4.3 GB of PFMs and most of a
@@ -365,7 +368,9 @@ int main(int argc, char** argv) {
       store.hand_over(seq, k, level, nSlots >= nOwned);
       tUpload += t.s();
       DERP_OK(ctx, derp_seq_level_compute_frame(seq, level, owned[k]));
-      if (so.do_temporal_filter) {
+      // (only at the two finest levels: above them a level's files are a few MB, and waiting for the GPU once per
+      // frame instead of once per level costs more than they do)
+      if (so.do_temporal_filter && level <= J.levelEnd + 1) {
         const int ready = nFiltered;  // filtered in an earlier iteration: their kernels ran before this frame's compute
         while (nFiltered < nOwned) {
           const int rc = derp_seq_level_filter_frame(seq, level, owned[nFiltered]);
@@ -376,8 +381,7 @@ int main(int argc, char** argv) {
           ++nFiltered;
         }
         for (; nSaved < ready; ++nSaved) {
-          writer.save_seq(seq, owned[nSaved], parity, frameBytes * nSaved, level, zero_pad(owned[nSaved]), dirs,
-                          level == J.levelEnd, true);
+          writer.save_seq(seq, owned[nSaved], level, zero_pad(owned[nSaved]), dirs, level == J.levelEnd, true);
         }
       }
     }
@@ -406,11 +410,18 @@ int main(int argc, char** argv) {
     }
     for (int k = nSaved; k < nOwned; ++k) {
       // PNG only at the finest level: the pipeline forces PFM above it (pipeline.py:366-369)
-      writer.save_seq(seq, owned[k], parity, frameBytes * k, level, zero_pad(owned[k]), dirs, level == J.levelEnd);
+      writer.save_seq(seq, owned[k], level, zero_pad(owned[k]), dirs, level == J.levelEnd);
     }
+    LOG_INFO(fmt("-- level %d: %.3fs (waited for decode %.3fs, input hand-over %.3fs, result downloads incl. waiting for "
+                 "the GPU %.3fs, waited for a free download plane %.3fs)", level, total.s() - lv0, store.waited - dec0,
+                 tUpload - up0, writer.downloading - dl0, writer.waited - wr0));
     LOG_INFO(fmt("-- Elapsed time: %.3fs wall (level %d)", total.s(), level));
   }
-  writer.finish();
+  {
+    Timer t;
+    writer.finish();
+    LOG_INFO(fmt("-- waited %.3fs for the last files", t.s()));
+  }
   if (useFiles) {
     LOG_INFO(fmt("-- rank %d: halo exchange through files: %.1f MB received, %.3fs", rank, files.received / 1e6, files.seconds));
   }
@@ -427,7 +438,11 @@ int main(int argc, char** argv) {
   char name[256];
   derp_device_name(ctx, name, sizeof name);
   LOG_INFO(fmt("-- TOTAL: %.3fs wall on %s (rank %d of %d)", total.s(), name, rank, world));
-  derp_seq_destroy(seq);
-  derp_destroy(ctx);
+  {
+    Timer t;
+    derp_seq_destroy(seq);
+    derp_destroy(ctx);
+    LOG_INFO(fmt("-- released the device in %.3fs", t.s()));
+  }
   return EXIT_SUCCESS;
 }

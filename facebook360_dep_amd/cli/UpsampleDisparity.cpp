@@ -101,9 +101,8 @@ int main(int argc, char** argv) {
         const int radius = (int)(scale * scale + 1);
         LOG_INFO(fmt("Applying filter with radius %d to %dx%d disparity to %s...", radius, wUp, hUp, rigDst[i].id));
         const std::vector<uint16_t> c16 = load_color_bgr16(image_path(F.s("color"), rigDst[i].id, frame), w2, h2);
-        CHECK_MSG(w2 >= wUp && h2 >= hUp,
-                  "colour guide smaller than the output resolution (the pipeline passes the smallest colour level "
-                  "that is at least as large, pipeline.py:410-411)");
+        // a guide of any size is resized to the output (cv_util::resizeImage, CvUtil.h:139-147): INTER_AREA when it is
+        // larger — what the pipeline passes (pipeline.py:410-411) — and OpenCV's bilinear emulation of it when smaller
         std::vector<float> guide(c16.size());
         const float s = 1.0f / 65535.0f;  // loadImage<Vec3f>: convertTo(CV_32F, 1/65535)
         for (size_t k = 0; k < c16.size(); ++k) {

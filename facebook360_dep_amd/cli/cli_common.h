@@ -1075,7 +1075,10 @@ inline void pyramid_level_sizes(std::map<int, std::pair<int, int>>& sizes, const
 // (ThreadPool.h); here the compute is the GPU's.
 struct IoPool {
   std::vector<std::thread> workers;
-  std::deque<std::function<void()>> queue;
+  // three classes of work, served in this order: 0 = staging copies the GPU-feeding thread waits for, 1 = result
+  // files (their download buffers are recycled two levels later), 2 = everything else (decoding the inputs, which is
+  // queued long in advance: a FIFO would park a level's few small writes behind a second of PNG inflation)
+  std::deque<std::function<void()>> queue[3];
   std::mutex mu;
   std::condition_variable cvWork, cvIdle;
   int busy = 0;
@@ -1128,12 +1131,17 @@ struct IoPool {
           std::function<void()> job;
           {
             std::unique_lock<std::mutex> lk(mu);
-            cvWork.wait(lk, [this] { return stop || !queue.empty(); });
-            if (queue.empty()) {
+            cvWork.wait(lk, [this] { return stop || pending_locked(); });
+            if (!pending_locked()) {
               return;
             }
-            job = std::move(queue.front());
-            queue.pop_front();
+            for (auto& q : queue) {
+              if (!q.empty()) {
+                job = std::move(q.front());
+                q.pop_front();
+                break;
+              }
+            }
             ++busy;
           }
           job();
@@ -1146,26 +1154,21 @@ struct IoPool {
       });
     }
   }
-  // urgent: ahead of everything queued (the staging copies the GPU-feeding thread waits for must not sit behind a
-  // second's worth of file writes)
-  void submit(std::function<void()> job, bool urgent = false) {
+  bool pending_locked() const { return !queue[0].empty() || !queue[1].empty() || !queue[2].empty(); }
+  void submit(std::function<void()> job, int prio = 2) {
     if (workers.empty()) {
       job();
       return;
     }
     {
       std::lock_guard<std::mutex> lk(mu);
-      if (urgent) {
-        queue.push_front(std::move(job));
-      } else {
-        queue.push_back(std::move(job));
-      }
+      queue[std::min(std::max(prio, 0), 2)].push_back(std::move(job));
     }
     cvWork.notify_one();
   }
   void wait_idle() {
     std::unique_lock<std::mutex> lk(mu);
-    cvIdle.wait(lk, [this] { return queue.empty() && busy == 0; });
+    cvIdle.wait(lk, [this] { return !pending_locked() && busy == 0; });
   }
   ~IoPool() {
     {
@@ -1184,7 +1187,7 @@ struct IoBatch {
   std::condition_variable cv;
   int pending = 0;
   std::string error;  // first fatal error of a job; re-raised by wait() on the waiting thread
-  void add(IoPool& pool, std::function<void()> job, bool urgent = false) {
+  void add(IoPool& pool, std::function<void()> job, int prio = 2) {
     {
       std::lock_guard<std::mutex> lk(mu);
       ++pending;
@@ -1206,7 +1209,7 @@ struct IoBatch {
       }
       --pending;
       cv.notify_all();
-    }, urgent);
+    }, prio);
   }
   bool done() {
     std::lock_guard<std::mutex> lk(mu);

@@ -552,19 +552,35 @@ struct FrameStore {
   // Out of core the library streams from the (pageable) buffers itself, whenever the frame's level is needed.
   static constexpr int kBounce = 4;
   Arena bounce[kBounce];
+  // page-lock the bounce planes at the finest level's size once (on whichever thread calls this), not level by level
+  void reserve_bounce(int level) {
+    const size_t bytes = J.npx(level) * 3 * sizeof(uint16_t);
+    for (auto& b : bounce) {
+      b.ensure(bytes);
+    }
+  }
   IoBatch bounceReady[kBounce];
   void hand_over(derp_seq* seq, int k, int level, bool resident) {
     derp_ctx* ctx = J.ctx;
     Level& L = data[k][level];
     const size_t plane = J.npx(level) * 3;  // u16 elements of one camera's image
-    const bool ring = resident && !L.color.empty() && plane * sizeof(uint16_t) >= (4u << 20);
+    // Every level but the thumbnails goes through the page-locked bounce planes and the copy stream (the other path
+    // copies on the COMPUTE stream and waits for it). Planes under 4 MB are copied into the bounce plane right here: a
+    // free pool thread can be a whole PNG inflation away. (Handing the runtime the pageable buffer directly — one
+    // call for all planes — took 25 ms per frame at the 256-px level while the inflation had every CPU busy.)
+    const bool ring = resident && !L.color.empty() && plane * sizeof(uint16_t) >= (64u << 10);
     if (ring) {
+      const bool inlineCopy = plane * sizeof(uint16_t) < (4u << 20);
       auto stage = [&](int s) {
         Arena& A = bounce[s % kBounce];
         A.ensure(plane * sizeof(uint16_t));
         void* dst = A.p;
         const uint16_t* src = L.color.data() + plane * s;
-        bounceReady[s % kBounce].add(pool, [=] { memcpy(dst, src, plane * sizeof(uint16_t)); }, true);
+        if (inlineCopy) {
+          memcpy(dst, src, plane * sizeof(uint16_t));
+        } else {
+          bounceReady[s % kBounce].add(pool, [=] { memcpy(dst, src, plane * sizeof(uint16_t)); }, 0);
+        }
       };
       for (int s = 0; s < std::min(kBounce, J.S); ++s) {
         stage(s);
@@ -610,6 +626,9 @@ struct LevelWriter {
     finish();
     arena[0].release();
     arena[1].release();
+    for (auto& r : ring) {
+      r.mem.release();
+    }
   }
   // make arena[parity] (>= bytes) available: the files written from it earlier are on disk
   void begin(int parity, size_t bytes) {
@@ -643,33 +662,93 @@ struct LevelWriter {
             write_exr_f32(base / (frameName + ".exr"), disp, w, h);
           }
         }
-      });
+      }, 1);
     }
   }
-  // a sequence frame's level (resident slot or out-of-core host store) instead of the selected frame's
+  // DerpSequence: a frame's level leaves through one of a few per-frame buffers — ONE download for all D planes (a
+  // copy call costs ~0.5 ms whatever its size, and there are 16 planes x 8 frames x 10 levels), D write jobs that
+  // share the buffer, and the buffer is free again when the last of them is done. The buffers are plain heap memory
+  // unless DERP_PIN_DOWNLOADS is set: page-locking what the two finest levels of an 8-frame chunk need (2.6 GB) costs
+  // 0.4 s and stalls every other HIP call of the process meanwhile, whichever thread does it, while the copy into
+  // pageable memory fits the slack the host thread has behind each frame's compute.
+  struct FrameBuf {
+    Arena mem;
+    int writers = 0;  // write jobs still reading it; 0 = free
+  };
+  std::vector<FrameBuf> ring;
+  std::mutex ringMu;
+  std::condition_variable ringCv;
+  IoBatch ringBatch;
+  bool pinRing = getenv("DERP_PIN_DOWNLOADS") != nullptr;
+  void reserve_ring(int slots) { ring.resize(slots); }
+  int ring_acquire(size_t bytes, int writers) {
+    Timer t;
+    int got = -1;
+    {
+      std::unique_lock<std::mutex> lk(ringMu);
+      ringCv.wait(lk, [&] {
+        for (size_t i = 0; i < ring.size(); ++i) {
+          if (ring[i].writers == 0) {
+            got = (int)i;
+            return true;
+          }
+        }
+        return false;
+      });
+      ring[got].writers = writers;
+    }
+    waited += t.s();
+    Arena& A = ring[got].mem;
+    if (A.bytes < bytes) {
+      if (pinRing) {
+        A.ensure(bytes);
+      } else {
+        A.release();
+        A.p = malloc(bytes);
+        CHECK_MSG(A.p != nullptr, "out of host memory");
+        A.pinned = false;
+        A.bytes = bytes;
+      }
+    }
+    return got;
+  }
+  void ring_release(int i) {
+    bool freed;
+    {
+      std::lock_guard<std::mutex> lk(ringMu);
+      freed = --ring[i].writers == 0;
+    }
+    if (freed) {
+      ringCv.notify_one();
+    }
+  }
+  // a sequence frame's level (resident slot or out-of-core host store) instead of the selected frame's.
   // fromScratch: the frame was filtered ahead of the level's Transfer (derp_seq_level_filter_frame); its filtered
   // level comes from the filter's scratch over the copy stream while the following frames compute
-  void save_seq(derp_seq* seq, int frame, int parity, size_t offset, int level, const std::string& frameName,
-                const std::vector<fs::path>& dirs, bool pngToo, bool fromScratch = false) {
+  void save_seq(derp_seq* seq, int frame, int level, const std::string& frameName, const std::vector<fs::path>& dirs,
+                bool pngToo, bool fromScratch = false) {
     derp_ctx* ctx = J.ctx;
     const int w = J.W[level], h = J.H[level];
     const bool png = J.savePng && pngToo, exr = J.saveExr && pngToo;
-    for (int d = 0; d < J.D; ++d) {
-      float* disp = reinterpret_cast<float*>(static_cast<char*>(arena[parity].p) + offset) + J.npx(level) * d;
-      {
-        Timer t;
-        if (fromScratch) {
-          DERP_OK(ctx, derp_seq_download_filtered(seq, frame, level, d, disp));
-        } else {
-          DERP_OK(ctx, derp_seq_download_disparity(seq, frame, level, d, disp));
-        }
-        downloading += t.s();
+    const size_t n = J.npx(level);
+    const int slot = ring_acquire(n * sizeof(float) * J.D, J.D);
+    float* all = static_cast<float*>(ring[slot].mem.p);
+    {
+      Timer t;
+      if (fromScratch) {
+        DERP_OK(ctx, derp_seq_download_filtered(seq, frame, level, -1, all));
+      } else {
+        DERP_OK(ctx, derp_seq_download_disparity(seq, frame, level, -1, all));
       }
+      downloading += t.s();
+    }
+    for (int d = 0; d < J.D; ++d) {
+      const float* disp = all + n * d;
       std::vector<fs::path> bases;
       for (const auto& dir : dirs) {
         bases.push_back(DerpJob::levelDir(dir, level) / J.rigDst[d].id);
       }
-      batch[parity].add(pool, [=] {
+      ringBatch.add(pool, [=] {
         for (const auto& base : bases) {
           write_pfm(base / (frameName + ".pfm"), disp, w, h);
           if (png) {
@@ -679,13 +758,15 @@ struct LevelWriter {
             write_exr_f32(base / (frameName + ".exr"), disp, w, h);
           }
         }
-      });
+        ring_release(slot);
+      }, 1);
     }
   }
   void finish() {
     Timer t;
     batch[0].wait();
     batch[1].wait();
+    ringBatch.wait();
     waited += t.s();
   }
 };

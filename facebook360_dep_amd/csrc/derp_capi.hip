@@ -395,7 +395,18 @@ int get_area_tab(derp_ctx* c, int ssize, int dsize, AreaTabDev** out, bool force
 // cv2.resize(src, (dw, dh), INTER_AREA): kind 0 BGR u16 -> BGRX, 1 u8 (-> {0,1} when threshold >= 0), 2 f32
 int resize_area_dev(derp_ctx* c, int kind, const void* src, int sw, int sh, void* dst, int dw, int dh, int threshold) {
   if (dw > sw || dh > sh) {
-    return fail(c, "pyramid levels must not be larger than the full-size frame (%dx%d -> %dx%d)", sw, sh, dw, dh);
+    // enlarging along an axis: cv::resize(INTER_AREA) turns into its bilinear emulation (float images only here)
+    if (kind < 2) {
+      return fail(c, "pyramid levels must not be larger than the full-size frame (%dx%d -> %dx%d)", sw, sh, dw, dh);
+    }
+    const dim3 g = grid2d(dw, dh, 1, kBlk2d);
+    if (kind == 3) {
+      hipLaunchKernelGGL(k_resize_linear_area_f32<3>, g, kBlk2d, 0, c->stream, (const float*)src, sw, sh, (float*)dst, dw, dh);
+    } else {
+      hipLaunchKernelGGL(k_resize_linear_area_f32<1>, g, kBlk2d, 0, c->stream, (const float*)src, sw, sh, (float*)dst, dw, dh);
+    }
+    KCHECK(c);
+    return 0;
   }
   AreaTabDev *tx, *ty;
   TRY(get_area_tab(c, sw, dw, &tx));
@@ -1232,6 +1243,13 @@ int derp_frame_slots(const derp_ctx* c, int* n_slots, int* selected) {
   return 0;
 }
 
+int derp_bind_thread(derp_ctx* c) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  return 0;
+}
 void* derp_host_alloc(size_t bytes) {
   void* p = nullptr;
   if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {

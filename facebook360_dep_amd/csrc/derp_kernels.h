@@ -1975,6 +1975,52 @@ __device__ __forceinline__ float area_src(const void* src, size_t pix, int c) {
   }
 }
 
+// cv::resize(INTER_AREA) when the image is ENLARGED along an axis: OpenCV emulates it with its bilinear machinery and
+// area-mode taps (resize.cpp; oracle_cv.h resizeLinearAreaF32 spells the rule out): per axis
+//   s = floor(d * scale), f = (d + 1) - (s + 1) / scale, f = f <= 0 ? 0 : f - floor(f); weights (1 - f, f);
+// a second tap beyond the last column is dropped (first tap x 1); rows are clamped. Horizontal pass, then vertical.
+// CN = 1 (float) or 3 (Vec3f: cv_util::resizeImage of UpsampleDisparity's colour guide, CvUtil.h:139-147).
+__device__ __forceinline__ void linear_area_tap(int d, int ssize, int dsize, int& s0, float& f, bool& one) {
+  const double inv_scale = (double)dsize / (double)ssize, scale = 1. / inv_scale;
+  int sx = (int)floor((double)d * scale);
+  float fx = (float)((double)(d + 1) - (double)(sx + 1) * inv_scale);
+  fx = fx <= 0 ? 0.f : fx - floorf(fx);
+  if (sx < 0) {
+    fx = 0.f;
+    sx = 0;
+  }
+  one = sx + 1 >= ssize;
+  if (sx >= ssize - 1) {
+    fx = 0.f;
+    sx = ssize - 1;
+  }
+  s0 = sx;
+  f = fx;
+}
+template <int CN>
+__global__ void k_resize_linear_area_f32(const float* __restrict__ src, int SW, int SH, float* __restrict__ dst, int DW,
+                                         int DH) {
+  const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
+  if (dx >= DW || dy >= DH) {
+    return;
+  }
+  int sx, sy;
+  float fx, fy;
+  bool onex, oney;
+  linear_area_tap(dx, SW, DW, sx, fx, onex);
+  linear_area_tap(dy, SH, DH, sy, fy, oney);
+  const int y0 = min(max(sy, 0), SH - 1), y1 = min(max(sy + 1, 0), SH - 1);
+  const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+  for (int c = 0; c < CN; ++c) {
+    const float* r0 = src + ((size_t)y0 * SW + sx) * CN + c;
+    const float* r1 = src + ((size_t)y1 * SW + sx) * CN + c;
+    const float h0 = onex ? r0[0] * 1.f : r0[0] * a0 + r0[CN] * a1;
+    const float h1 = onex ? r1[0] * 1.f : r1[0] * a0 + r1[CN] * a1;
+    dst[((size_t)dy * DW + dx) * CN + c] = h0 * b0 + h1 * b1;
+  }
+}
+
 template <int KIND>
 __global__ void k_resize_area(const void* __restrict__ src, int SW, int SH, void* __restrict__ dst, int DW, int DH,
                               AreaAxis ax, AreaAxis ay, int threshold) {

@@ -1051,18 +1051,27 @@ int derp_seq_download_disparity(derp_seq* q, int frame, int level, int d, float*
   derp_ctx* c = q->c;
   TRY(check_level(c, level));
   const int k = owned_index(q, frame);
-  if (k < 0 || d < 0 || d >= c->D || !disp) {
+  if (k < 0 || d < -1 || d >= c->D || !disp) {
     return fail(c, "bad frame / destination index / null output");
   }
+  const size_t n = npx(c, level);
   if (q->streaming) {
     if (!q->hostHave[(size_t)k * c->numLevels + level]) {
       return fail(c, "level %d of frame %d has not been processed", level, frame);
     }
-    memcpy(disp, q->hostDisp[k][level] + (size_t)d * npx(c, level), npx(c, level) * sizeof(float));
+    memcpy(disp, q->hostDisp[k][level] + (size_t)std::max(d, 0) * n, (d < 0 ? c->D : 1) * n * sizeof(float));
     return 0;
   }
   HIPCHK(c, hipSetDevice(c->device));
   TRY(select_frame(c, k));
+  if (d < 0) {  // every destination's plane in one copy, [D][h*w]
+    if (!c->haveDisp[level]) {
+      return fail(c, "level %d has not been processed", level);
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(disp, c->pyrDisp[level].p, n * c->D * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+  }
   return derp_download_disparity(c, level, d, disp);
 }
 
@@ -1272,7 +1281,7 @@ int derp_seq_download_filtered(derp_seq* q, int frame, int level, int d, float* 
   derp_ctx* c = q->c;
   TRY(check_level(c, level));
   const int k = owned_index(q, frame);
-  if (k < 0 || d < 0 || d >= c->D || !out) {
+  if (k < 0 || d < -1 || d >= c->D || !out) {
     return fail(c, "bad frame / destination index / null output");
   }
   if (q->streaming || q->filteredAt[k] != level) {
@@ -1281,8 +1290,9 @@ int derp_seq_download_filtered(derp_seq* q, int frame, int level, int d, float* 
   HIPCHK(c, hipSetDevice(c->device));
   const size_t n = npx(c, level);
   HIPCHK(c, hipStreamWaitEvent(c->copyStream, q->filteredEv[k], 0));
-  HIPCHK(c, hipMemcpyAsync(out, q->filtered[k].as<float>() + (size_t)d * n, n * sizeof(float), hipMemcpyDeviceToHost,
-                           c->copyStream));
+  // dst = -1: every destination's plane in one copy, [D][h*w]
+  HIPCHK(c, hipMemcpyAsync(out, q->filtered[k].as<float>() + (size_t)std::max(d, 0) * n, (d < 0 ? c->D : 1) * n * sizeof(float),
+                           hipMemcpyDeviceToHost, c->copyStream));
   HIPCHK(c, hipStreamSynchronize(c->copyStream));
   return 0;
 }

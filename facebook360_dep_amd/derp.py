@@ -63,7 +63,7 @@ EXPORTS = [
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
     "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
-    "derp_set_frame_slots", "derp_select_frame", "derp_frame_slots", "derp_host_alloc", "derp_host_free", "derp_host_register", "derp_host_unregister",
+    "derp_set_frame_slots", "derp_select_frame", "derp_frame_slots", "derp_host_alloc", "derp_host_free", "derp_bind_thread", "derp_host_register", "derp_host_unregister",
     "derp_seq_options_default", "derp_seq_window", "derp_seq_owner", "derp_seq_plan", "derp_seq_create", "derp_seq_destroy",
     "derp_seq_counts", "derp_seq_frames", "derp_seq_frame_slot", "derp_seq_buffer", "derp_rccl_unique_id",
     "derp_seq_attach_rccl", "derp_seq_attach_loopback", "derp_seq_attach_external", "derp_seq_selftest",

@@ -100,6 +100,9 @@ int derp_frame_slots(const derp_ctx* ctx, int* n_slots, int* selected);
  * derp_host_alloc returns NULL on failure (callers fall back to malloc). */
 void* derp_host_alloc(size_t bytes);
 void derp_host_free(void* p);
+/* make the context's device current on the CALLING thread: a worker thread that allocates page-locked memory
+ * (derp_host_alloc) or registers buffers for a context created on another thread calls this first */
+int derp_bind_thread(derp_ctx* ctx);
 /* page-lock / release memory the caller allocated itself (image buffers decoded before the runtime was up):
  * uploads from it then run at the PCIe rate. derp_host_register returns non-zero when the runtime refuses; the
  * memory stays usable, only slower. */
@@ -306,7 +309,7 @@ int derp_seq_upload_color_plane(derp_seq* seq, int frame, int level, int src, co
 /* level disparity of an owned frame, whichever mode: upload = the previous level read back from disk when a run
  * resumes (DerpCLI.cpp:287-288); download = the level's result (filtered when the temporal filter is on) */
 int derp_seq_upload_disparity(derp_seq* seq, int frame, int level, int dst, const float* disparity);
-int derp_seq_download_disparity(derp_seq* seq, int frame, int level, int dst, float* disparity);
+int derp_seq_download_disparity(derp_seq* seq, int frame, int level, int dst, float* disparity);  /* dst = -1: all, [D][h*w] */
 /* buffer of an owned or halo frame: kind 0 colour [S][h*w] BGRX u16, 1 fg mask [S][h*w] u8,
  * 2 level disparity [D][h*w] f32 */
 int derp_seq_buffer(derp_seq* seq, int frame, int level, int kind, void** ptr, size_t* bytes);
@@ -334,7 +337,8 @@ int derp_seq_level_filter(derp_seq* seq, int level);       /* temporal filter of
  * (TemporalBilateralFilter.cpp:139-184 per frame). The result stays in the frame's scratch; the Transfer is still
  * derp_seq_level_filter's. Returns 0 = filtered, 2 = not possible yet / out of core / filter off (no error), 1 = error. */
 int derp_seq_level_filter_frame(derp_seq* seq, int level, int frame);
-/* ... and its download from that scratch, on the copy stream (the compute stream keeps running) */
+/* ... and its download from that scratch, on the copy stream (the compute stream keeps running); dst = -1: every
+ * destination's plane in one copy, [D][h*w] */
 int derp_seq_download_filtered(derp_seq* seq, int frame, int level, int dst, float* disparity);
 int derp_seq_run(derp_seq* seq, int level_start, int level_end);
 int derp_seq_stats(derp_seq* seq, uint64_t* bytes_sent, uint64_t* bytes_received, double* exchange_ms);

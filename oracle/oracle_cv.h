@@ -416,6 +416,66 @@ resizeAreaGeneric(const T* src, int sw, int sh, int dw, int dh, T* dst, Cast cas
   }
 }
 
+// cv::resize(..., INTER_AREA) when the image is ENLARGED along at least one axis (resize.cpp: "true area interpolation
+// is only implemented for the case scale_x >= 1 && scale_y >= 1; in other cases it is emulated using some variant of
+// bilinear"): the INTER_LINEAR machinery (ksize 2) with the area-mode tap positions and weights
+//   sx = floor(dx * scale), fx = (dx + 1) - (sx + 1) * inv_scale, fx = fx <= 0 ? 0 : fx - floor(fx)
+// on BOTH axes, float weights (1 - fx, fx), taps past the last column read as the last column times 1, rows clamped;
+// horizontal pass first, then the vertical one (HResizeLinear / VResizeLinear<float>, scalar order, no FMA).
+// Needed by cv_util::resizeImage<Vec3f> (CvUtil.h:139-147) when UpsampleDisparity's colour guide is smaller than the
+// output (UpsampleDisparity.cpp:117). Float images only. Unpinned like every OpenCV primitive here.
+struct LinearAreaAxis {
+  std::vector<int> ofs;
+  std::vector<float> w1;  // weight of tap ofs + 1; weight of tap ofs is 1 - w1
+  std::vector<char> one;  // the second tap lies beyond the image: the first tap alone, times 1
+};
+static inline void linearAreaAxis(int ssize, int dsize, LinearAreaAxis& a) {
+  const double inv_scale = (double)dsize / ssize, scale = 1. / inv_scale;
+  a.ofs.resize(dsize);
+  a.w1.resize(dsize);
+  a.one.resize(dsize);
+  for (int dx = 0; dx < dsize; ++dx) {
+    int sx = cvFloorD(dx * scale);
+    float fx = (float)((dx + 1) - (sx + 1) * inv_scale);
+    fx = fx <= 0 ? 0.f : fx - (float)cvFloorD(fx);
+    if (sx < 0) {
+      fx = 0, sx = 0;
+    }
+    a.one[dx] = sx + 1 >= ssize;
+    if (sx >= ssize - 1) {
+      fx = 0, sx = ssize - 1;
+    }
+    a.ofs[dx] = sx;
+    a.w1[dx] = fx;
+  }
+}
+template <int CN>
+static inline void resizeLinearAreaF32(const float* src, int sw, int sh, float* dst, int dw, int dh) {
+  LinearAreaAxis ax, ay;
+  linearAreaAxis(sw, dw, ax);
+  linearAreaAxis(sh, dh, ay);
+  std::vector<float> r0((size_t)dw * CN), r1((size_t)dw * CN);
+  auto hrow = [&](int sy, std::vector<float>& out) {
+    const float* S = src + (size_t)sy * sw * CN;
+    for (int dx = 0; dx < dw; ++dx) {
+      const int sx = ax.ofs[dx];
+      for (int c = 0; c < CN; ++c) {
+        out[(size_t)dx * CN + c] = ax.one[dx] ? S[sx * CN + c] * 1.f
+                                              : S[sx * CN + c] * (1.f - ax.w1[dx]) + S[(sx + 1) * CN + c] * ax.w1[dx];
+      }
+    }
+  };
+  for (int dy = 0; dy < dh; ++dy) {
+    const int sy = ay.ofs[dy];
+    hrow(std::min(std::max(sy, 0), sh - 1), r0);
+    hrow(std::min(std::max(sy + 1, 0), sh - 1), r1);
+    const float b0 = 1.f - ay.w1[dy], b1 = ay.w1[dy];
+    for (int i = 0; i < dw * CN; ++i) {
+      dst[(size_t)dy * dw * CN + i] = r0[i] * b0 + r1[i] * b1;
+    }
+  }
+}
+
 // cv::resize(..., INTER_AREA) as resize.cpp dispatches it when shrinking:
 //   * both scale factors integer ("is_area_fast"):
 //       - scale 2x2 on 8U/16U: ResizeAreaFastVec_SIMD_*: (a + b + c + d + 2) >> 2
@@ -439,6 +499,12 @@ static inline void resizeAreaCv(const T* src, int sw, int sh, T* dst, int dw, in
   };
   if (sw == dw && sh == dh) {
     memcpy(dst, src, sizeof(T) * (size_t)sw * sh * CN);
+    return;
+  }
+  if (scale_x < 1 || scale_y < 1) {  // enlarging along an axis: the bilinear emulation (float images only here)
+    if constexpr (std::is_same<T, float>::value) {
+      resizeLinearAreaF32<CN>(src, sw, sh, dst, dw, dh);
+    }
     return;
   }
   if (fast) {

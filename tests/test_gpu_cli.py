@@ -428,11 +428,20 @@ def test_upsample_cli(dataset, tmp_path):
             ref = O.joint_bilateral_f32(ref, guide, np.ones((h_out, w_out), np.uint8), radius, 0.05, 0.5, 0.5, 1.0)
             got = dio.read_pfm(os.path.join(up_c, cam, "000000.pfm"))
             assert common.compare_disparity(got, ref, 1e-5)[0] == 0, (w_out, cam)
-    # a guide smaller than the output is refused loudly
-    p = run("UpsampleDisparity", "--rig=" + rigf, "--disparity=" + lvl2, "--output=" + str(tmp_path / "up_e"),
-            "--resolution=%d" % w_up, "--color=" + os.path.join(root, "video", "color_levels", "level_1"),
-            expect_ok=False)
-    assert p.returncode != 0 and "colour guide smaller" in p.stderr
+    # (e) a guide SMALLER than the output is enlarged the way cv::resize(INTER_AREA) enlarges (its bilinear emulation,
+    # CvUtil.h:139-147): level-1 colour (64 px) for the 96-px output
+    up_e = str(tmp_path / "up_e")
+    run("UpsampleDisparity", "--rig=" + rigf, "--disparity=" + lvl2, "--output=" + up_e, "--resolution=%d" % w_up,
+        "--color=" + os.path.join(root, "video", "color_levels", "level_1"))
+    for d, cam in enumerate(ids):
+        disp = dio.read_pfm(os.path.join(lvl2, cam, "000000.pfm"))
+        guide = O.cv_resize_area(fr["color"][1][d].astype(np.float32) * np.float32(1.0 / 65535.0), w_up, h_up)
+        assert guide.shape == (h_up, w_up, 3)
+        radius = O.upsample_radius(disp.shape[1], w_up)
+        ref = O.upsample_disparity(rd, d, disp, w_up, h_up)
+        ref = O.joint_bilateral_f32(ref, guide, np.ones((h_up, w_up), np.uint8), radius, 0.05, 0.5, 0.5, 1.0)
+        got = dio.read_pfm(os.path.join(up_e, cam, "000000.pfm"))
+        assert common.compare_disparity(got, ref, 1e-5)[0] == 0, cam
 
 
 def test_layer_disparities_cli(dataset, tmp_path):

@@ -831,6 +831,20 @@ def test_resize_area_vec3f(gpu):
         want = O.cv_resize_area(src, dw, dh)
         assert got.shape == want.shape == (dh, dw, 3)
         assert _float_equal(got, want) == 0, (dw, dh)
+    # ENLARGED along at least one axis: cv::resize(INTER_AREA) emulates area interpolation with its bilinear machinery
+    # and area-mode taps (a colour guide smaller than UpsampleDisparity's output): integer and fractional factors, one
+    # axis only, one axis up and the other down, scalar float planes
+    for (dw, dh) in [(240, 180), (360, 270), (151, 113), (120, 200), (300, 90), (200, 45), (60, 180)]:
+        got = gpu.resize_area(src, dw, dh)
+        want = O.cv_resize_area(src, dw, dh)
+        assert got.shape == want.shape == (dh, dw, 3)
+        assert _float_equal(got, want) == 0, (dw, dh)
+        # sanity of the restatement itself: a convex combination of source texels, exact on a constant image
+        assert want.min() >= src.min() and want.max() <= src.max()
+    flat = np.full((40, 50, 3), np.float32(0.3))
+    assert np.allclose(O.cv_resize_area(flat, 125, 73), 0.3, rtol=0, atol=1e-7)
+    plane = rng.random((31, 47), dtype=np.float32)
+    assert _float_equal(gpu.resize_area(plane, 100, 64), O.cv_resize_area(plane, 100, 64)) == 0
 
 
 def test_generate_foreground_mask(gpu):

@@ -220,3 +220,29 @@ def test_ssim_vs_float64():
     assert abs(avg[0] - sel[:, 0].mean()) < 1e-12
     assert abs(avg[1] - np.nanmean(sel[:, 1])) < 1e-12
     assert O.format_results([0.5, 0.25, 0.125]) == "R 12.50%, G 25.00%, B 50.00%"
+
+
+def test_resize_area_enlargement_is_the_bilinear_emulation():
+    """cv::resize(INTER_AREA) on an image that is enlarged along an axis (oracle_cv.h resizeLinearAreaF32): with an
+    integer zoom factor every destination pixel lies inside one source pixel and the rule degenerates to pixel
+    replication (OpenCV's documentation: "when the image is zoomed, it is similar to the INTER_NEAREST method"); with
+    2 -> 3 pixels the middle one is the mean of both; a constant image stays constant; the result is a convex
+    combination of source texels."""
+    from oracle import oracle_lib as O
+
+    rng = np.random.default_rng(3)
+    src = rng.random((7, 9, 3), dtype=np.float32)
+    for k in (2, 3, 5):
+        got = O.cv_resize_area(src, 9 * k, 7 * k)
+        assert np.array_equal(got, np.repeat(np.repeat(src, k, axis=0), k, axis=1)), k
+    # one axis enlarged by an integer factor, the other untouched
+    assert np.array_equal(O.cv_resize_area(src, 18, 7), np.repeat(src, 2, axis=1))
+    row = np.array([[0.25, 0.75]], dtype=np.float32)
+    assert np.array_equal(O.cv_resize_area(row, 3, 1), np.array([[0.25, 0.5, 0.75]], dtype=np.float32))
+    plane = rng.random((11, 13), dtype=np.float32)
+    up = O.cv_resize_area(plane, 31, 17)
+    assert up.shape == (17, 31) and up.min() >= plane.min() and up.max() <= plane.max()
+    # corners are the source corners (first tap weight 1 at the start, clamped single tap at the end)
+    assert up[0, 0] == plane[0, 0] and up[-1, -1] == plane[-1, -1]
+    flat = np.full((5, 6), np.float32(0.7))
+    assert np.allclose(O.cv_resize_area(flat, 17, 9), 0.7, rtol=0, atol=2e-7)

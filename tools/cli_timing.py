@@ -31,18 +31,28 @@ print("dataset: %d frame(s) of %s written in %.1f s under %s" % (frames, cfg, ti
 extras = os.environ.get("CLI_EXTRA", "").split(";") if os.environ.get("CLI_EXTRA") else [""]
 outs = []
 for binary, threads, extra in [(b, t, e) for b in binary.split(",") for t in threads.split(",") for e in extras]:
-    out = os.path.join(root, "out_%s_%s_%d" % (binary, threads, len(outs)))
+    out = os.path.join(root, "out_%s_%s_%d" % (binary.replace("/", "_").replace("@", "_").replace("=", "_"), threads, len(outs)))
     outs.append(out)
     t0 = time.time()
-    p = subprocess.run([os.path.join(ROOT, "facebook360_dep_amd", "bin", binary), "--input_root=" + root,
+    # "<dir>/<binary>" = another build of the binary (A/B on one box: the round-3 build lives in bin_r3 with its library)
+    env = dict(os.environ)
+    label = binary
+    while "@" in binary:  # "KEY=VALUE@binary": that environment variable for this run
+        kv, binary = binary.split("@", 1)
+        env[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
+    exe = os.path.join(ROOT, "facebook360_dep_amd", binary) if "/" in binary else os.path.join(ROOT, "facebook360_dep_amd", "bin", binary)
+    if "/" in binary:
+        env["LD_LIBRARY_PATH"] = os.path.dirname(exe) + ":" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, "--input_root=" + root,
                         "--output_root=" + out, "--first=000000", "--last=%06d" % (frames - 1), "--resolution=%d" % res,
                         "--threads=" + threads] + (["--partial_coverage"] if n <= 4 else []) + extra.split(),
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=env)
     wall = time.time() - t0
     print("%s --threads=%s %s rc=%d, wall %.2f s for %d frame(s) = %.1f Mpix/s from disk to disk" % (
-        binary, threads, extra, p.returncode, wall, frames, frames * n * res * res / wall / 1e6))
+        label, threads, extra, p.returncode, wall, frames, frames * n * res * res / wall / 1e6))
     for line in p.stderr.splitlines():
         if "-- I/O" in line or "-- TOTAL" in line or "-- rank" in line or "-- inputs" in line or "-- start-up" in line or \
+                "-- level" in line or "-- waited" in line or "-- released" in line or \
                 re.search(r"\(level \d+\)$", line):
             print(line)
         if "frame slot(s) in HBM" in line:
