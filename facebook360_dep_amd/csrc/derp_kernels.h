@@ -61,6 +61,11 @@ namespace derp {
 #define DERP_MIX_HOT_ONLY 0
 #endif
 // computeSSD's 4x4-block arithmetic in plain fp32 (1) or packed fp32 (0), per kernel family
+// random proposals: each XCD walks its own band of tiles (1, like the coherent kernels) or all XCDs sweep the image
+// together (0: consecutive blocks, which the hardware deals round-robin to the XCDs, are neighbouring tiles)
+#ifndef DERP_RANDOM_SWIZZLE
+#define DERP_RANDOM_SWIZZLE 1
+#endif
 #ifndef DERP_RANDOM_SSD_SCALAR
 #define DERP_RANDOM_SSD_SCALAR 1
 #endif
@@ -138,7 +143,6 @@ __device__ __forceinline__ void tile_pixel(int item, int tilesX, int& x, int& y)
   const int lane = threadIdx.x & 63;
   const int gw = item * (int)(blockDim.x >> 6) + (int)(threadIdx.x >> 6);
   const int super = gw >> 2, quad = gw & 3;
-#if DERP_TILE_BLOCK > 1
   // super-tiles are walked in DERP_TILE_BLOCK x DERP_TILE_BLOCK squares (128 x 128 px for 8): the tiles an
   // XCD works on at one time then cover a compact square instead of a 16-px-high strip, which shrinks
   // the union of the source-image footprints their gathers fall into (tilesX is padded to the block size)
@@ -146,9 +150,6 @@ __device__ __forceinline__ void tile_pixel(int item, int tilesX, int& x, int& y)
   const int blk = super / (B * B), in = super % (B * B);
   const int blocksX = tilesX / B;
   const int tx = (blk % blocksX) * B + (in % B), ty = (blk / blocksX) * B + (in / B);
-#else
-  const int tx = super % tilesX, ty = super / tilesX;
-#endif
   x = tx * 16 + (quad & 1) * 8 + (lane & 7);
   y = ty * 16 + (quad >> 1) * 8 + (lane >> 3);
 }
@@ -1282,7 +1283,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
   const int dl = blockIdx.y;
   const int d = V.dst0 + dl;
   int x, y;
-  tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0), tilesX, x, y);
+  tile_pixel(DERP_RANDOM_SWIZZLE ? xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0) : (int)blockIdx.x, tilesX, x, y);
 #if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
   __shared__ double atanLut[kAtanLutDoubles];
   atan_lut_fill(atanLut);
