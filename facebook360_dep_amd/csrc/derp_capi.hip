@@ -141,6 +141,7 @@ struct derp_ctx {
 
   bool profiling = false;
   bool noMemo = false;  // DERP_NO_MEMO (developer switch), read once in derp_create
+  bool noTemporalTile = false;  // DERP_NO_TEMPORAL_TILE (developer A/B: the direct form of the temporal filter)
   std::vector<TimedSpan> spans;
   double accMs[ST_COUNT][kMaxLevels];
   int accLaunch[ST_COUNT][kMaxLevels];
@@ -967,8 +968,15 @@ int temporal_launch(derp_ctx* c, const void* const* guides, const float* const* 
     F.carry = n > kMaxTemporalFrames ? c->temporalCarry.as<float2>() : nullptr;
     F.first = t0 == 0;
     F.last = t0 + F.n >= n;
-    hipLaunchKernelGGL(k_temporal, grid2d(W, H, planes, kBlk2d), kBlk2d, 0, c->stream, F, W, H, sigma, radius, w0, w1, w2,
-                       out, dst2src);
+    // taps staged through LDS unless the halo makes the tile too big (two buffers of (32 + 2r) x (8 + 2r) x 9 bytes)
+    const size_t lds = 2 * ((((size_t)(32 + 2 * radius) * (8 + 2 * radius) * 9) + 15) & ~(size_t)15);
+    if (radius >= 0 && lds <= 48 * 1024 && !c->noTemporalTile) {
+      hipLaunchKernelGGL(k_temporal_tiled, grid2d(W, H, planes, kBlk2d), kBlk2d, lds, c->stream, F, W, H, sigma, radius, w0,
+                         w1, w2, out, dst2src);
+    } else {
+      hipLaunchKernelGGL(k_temporal, grid2d(W, H, planes, kBlk2d), kBlk2d, 0, c->stream, F, W, H, sigma, radius, w0, w1, w2,
+                         out, dst2src);
+    }
     KCHECK(c);
   }
   return 0;
@@ -1045,6 +1053,7 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
     c->xcdRotate = atoi(e);
   }
   c->noMemo = getenv("DERP_NO_MEMO") != nullptr;
+  c->noTemporalTile = getenv("DERP_NO_TEMPORAL_TILE") != nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking) != hipSuccess) {
     return bail("hipStreamCreate failed");
