@@ -124,6 +124,8 @@ struct derp_ctx {
   int DB = 0;  // dst batch that fits the table budget
   DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask, pairCount;
   DevBuf temporalCarry;  // accumulators of a temporal window longer than one launch holds
+  DevBuf tileSeen;       // k_reproject_bias: per (table, tile) whether any map position is valid
+  int colorTablesCleanLevel = -1;  // level whose colour / bias tables were written in full since its warps were built
   DevBuf projWarp, projColor, projBias, projWarpInv, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
   DevBuf rayDir, behind;  // per destination pixel: ray direction [3][D][n] f64, sources facing away [D][n] (k_pixel_rays)
   int warpCachedLevel = -1;
@@ -142,6 +144,7 @@ struct derp_ctx {
   bool profiling = false;
   bool noMemo = false;  // DERP_NO_MEMO (developer switch), read once in derp_create
   bool noTemporalTile = false;  // DERP_NO_TEMPORAL_TILE (developer A/B: the direct form of the temporal filter)
+  bool noBlankSkip = false;     // DERP_NO_BLANK_SKIP (developer A/B: every frame rewrites the blank tiles of the colour tables)
   std::vector<TimedSpan> spans;
   double accMs[ST_COUNT][kMaxLevels];
   int accLaunch[ST_COUNT][kMaxLevels];
@@ -541,6 +544,7 @@ int build_warp(derp_ctx* c, int dst0, int nd) {
   hipLaunchKernelGGL(k_pixel_rays, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->rayDir.as<double>(),
                      c->behind.as<unsigned>());
   KCHECK(c);
+  c->colorTablesCleanLevel = -1;  // new warps (another level, batch or rig state): the colour tables must be rewritten in full
   // ... and the inverse warps reprojectColors reads (projWarpInv, PyramidLevel.h:46-51)
   hipLaunchKernelGGL(k_proj_warp_inv, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->projWarpInv.as<float2>());
   KCHECK(c);
@@ -552,10 +556,15 @@ int build_color_tables(derp_ctx* c, int dst0, int nd) {
   LevelView V = make_view(c, ST_REPROJECT, dst0, nd);
   // colours and their 3x3 biases in one pass (the bias stage's time is inside ST_REPROJECT now)
   Span sp(c, ST_REPROJECT, L);
-  hipLaunchKernelGGL(k_reproject_bias, dim3((V.W + kRbTile - 1) / kRbTile, (V.H + kRbTile - 1) / kRbTile, nd * (c->S - 1)),
-                     dim3(256), 0, c->stream, V, c->projWarpInv.as<float2>(), c->projColor.as<ushort4>(),
-                     c->projBias.as<ushort4>());
+  const dim3 grid((V.W + kRbTile - 1) / kRbTile, (V.H + kRbTile - 1) / kRbTile, nd * (c->S - 1));
+  ALLOC(c, c->tileSeen, (size_t)grid.x * grid.y * grid.z);
+  // a frame that finds the tables of this level as an earlier frame left them (same warps: a sequence running the
+  // level frame after frame) skips the tiles no source pixel maps into — they still hold their zeros
+  const int skipBlank = c->colorTablesCleanLevel == L && nd == c->D && !c->noBlankSkip;
+  hipLaunchKernelGGL(k_reproject_bias, grid, dim3(256), 0, c->stream, V, c->projWarpInv.as<float2>(),
+                     c->projColor.as<ushort4>(), c->projBias.as<ushort4>(), c->tileSeen.as<uint8_t>(), skipBlank);
   KCHECK(c);
+  c->colorTablesCleanLevel = nd == c->D ? L : -1;
   return 0;
 }
 
@@ -1054,6 +1063,7 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
   }
   c->noMemo = getenv("DERP_NO_MEMO") != nullptr;
   c->noTemporalTile = getenv("DERP_NO_TEMPORAL_TILE") != nullptr;
+  c->noBlankSkip = getenv("DERP_NO_BLANK_SKIP") != nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking) != hipSuccess) {
     return bail("hipStreamCreate failed");
@@ -1119,7 +1129,7 @@ void derp_destroy(derp_ctx* c) {
   c->devMask.release();
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
                     &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
-                    &c->projWarp, &c->projColor, &c->projBias, &c->projWarpInv, &c->temporalCarry, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
+                    &c->projWarp, &c->projColor, &c->projBias, &c->projWarpInv, &c->temporalCarry, &c->tileSeen, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
   }

@@ -1050,11 +1050,21 @@ __global__ void k_proj_warp_inv(LevelView V, float2* __restrict__ warpInv) {
 // HBM what the remap had just written (19.7 GB per level-0 launch, 68 % of its wave-cycles waiting). Both tables
 // carry a 2-texel replicated ring: edge pixels write their ring texels too.
 constexpr int kRbTile = 32, kRbPitch = kRbTile + 2, kRbCells = kRbPitch * kRbPitch;
+// tileSeen [tables][tilesY][tilesX]: whether any position of the tile (halo included) has a valid map. The inverse warps
+// depend on the rig and the level size only, so a tile that is all-NaN for one frame is all-NaN for every frame: its
+// colour and bias texels are the constant border 0. skipBlank = 0: write everything and record the flags (the first
+// frame that runs a level after its tables were (re)built); 1: blocks of blank tiles return at once — the zeros the
+// first frame wrote are still there, nothing else writes these tables (on the 16-camera rig about half of the
+// (tile, source) combinations: the sources that face away from that part of the destination image).
 __global__ void __launch_bounds__(256)
     k_reproject_bias(LevelView V, const float2* __restrict__ warpInv, ushort4* __restrict__ projColor,
-                     ushort4* __restrict__ projBias) {
+                     ushort4* __restrict__ projBias, uint8_t* __restrict__ tileSeen, int skipBlank) {
   __shared__ ushort4 tile[kRbCells];
   const int tab = blockIdx.z;  // dl * (S - 1) + slot
+  uint8_t* seen = tileSeen + ((size_t)tab * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (skipBlank && !*seen) {
+    return;
+  }
   const int dl = tab / (V.S - 1), sl = tab - dl * (V.S - 1);
   const int own = V.dst2src[V.dst0 + dl];
   const int s = sl < own ? sl : sl + 1;
@@ -1063,16 +1073,22 @@ __global__ void __launch_bounds__(256)
   const size_t plane = (size_t)OW * OH, n = (size_t)V.W * V.H;
   const ushort4* img = V.srcColor + (size_t)s * n;
   const float2* map = warpInv + (size_t)tab * n;
+  int any = 0;
   for (int k = threadIdx.x; k < kRbCells; k += 256) {
     const int ty = k / kRbPitch, tx = k - ty * kRbPitch;
     const int qx = x0 - 1 + tx, qy = y0 - 1 + ty;
     if (qx >= -1 && qx <= V.W && qy >= -1 && qy <= V.H) {
       const float2 m = map[(size_t)reflect101(qy, V.H) * V.W + reflect101(qx, V.W)];
       // NaN map -> (-32768, -32768) in cv::remap's fixed point -> every tap outside -> constant border 0
-      tile[k] = (m.x != m.x) ? make_ushort4(0, 0, 0, 0) : remap_cubic_u16(img, V.W, V.H, m.x, m.y);
+      const bool valid = !(m.x != m.x);
+      any |= valid;
+      tile[k] = valid ? remap_cubic_u16(img, V.W, V.H, m.x, m.y) : make_ushort4(0, 0, 0, 0);
     }
   }
-  __syncthreads();
+  any = __syncthreads_or(any);
+  if (!skipBlank && threadIdx.x == 0) {
+    *seen = (uint8_t)(any != 0);
+  }
   ushort4* pc = projColor + (size_t)tab * plane;
   ushort4* pb = projBias + (size_t)tab * plane;
   const int lx = threadIdx.x & 31;
