@@ -406,9 +406,10 @@ def main():
         "dtype": "f32+f64",  # photometry in f32 over u16 texels; camera geometry in f64
         "data": "synthetic",
         "config": {
-            "workload": ("BASELINE config 3: %d-camera %dx%d synthetic rig, %d-frame sequence, full %d-level pyramid per "
+            "workload": ("BASELINE config %s: %d-camera %dx%d synthetic rig, %d-frame sequence, full %d-level pyramid per "
                          "frame, %s; the same sequence for every --gpus N (%s partition, %d frame(s) on this rank)"
-                         % (n_cams, res, res, args.frames, n_levels,
+                         % ({"cfg2": "3" if args.frames > 1 else "2", "cfg4": "4", "cfg1": "1"}.get(args.config, args.config),
+                            n_cams, res, res, args.frames, n_levels,
                             "per-level temporal filter (+-2 frames)" if temporal else "no temporal filter",
                             args.partition, frames_here)),
             "name": "cfg3" if (args.config == "cfg2" and args.frames == 8 and temporal) else args.config,

@@ -65,7 +65,9 @@ struct FileTransport {
     fs::create_directories(dir);
   }
   fs::path name(int level, int kind, const derp_seq_transfer& t) const {
-    return dir / fmt("L%d_k%d_f%06d_to%d.bin", level, kind, t.frame, t.to_rank);
+    // the launch's token is part of the name as well as of the content: a file some other launch left here is never
+    // the file this rank waits for
+    return dir / fmt("L%d_k%d_f%06d_to%d.%s.bin", level, kind, t.frame, t.to_rank, token.c_str());
   }
   void move(int level, int kind) {
     Timer tm;

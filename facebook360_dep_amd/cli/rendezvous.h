@@ -56,10 +56,24 @@ struct Rendezvous {
   void join() {
     Timer t;
     if (rank == 0) {
+      // The wipe must not race with the other ranks, which may already be answering the dead job's token inside the
+      // directory (a file appearing under remove_all's feet makes it stop half way and leaves the rest behind): move
+      // the old directory out of everybody's sight in one rename, then delete it at leisure.
       std::error_code ec;
-      fs::remove_all(dir, ec);
-      fs::create_directories(dir);
       token = random_word();
+      if (fs::exists(dir, ec)) {
+        const fs::path grave = dir.string() + ".dead." + token;
+        fs::rename(dir, grave, ec);
+        const fs::path victim = ec ? dir : grave;  // the rename itself failed -> wipe in place
+        for (int attempt = 0; attempt < 100; ++attempt) {
+          std::error_code ec2;
+          fs::remove_all(victim, ec2);
+          if (!fs::exists(victim, ec2)) {
+            break;
+          }
+        }
+      }
+      fs::create_directories(dir);
       publish(dir / "token", token);
       std::string go;
       for (int r = 1; r < world; ++r) {
