@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "../../include/derp_hip.h"
+#include "image_codecs.h"
 
 namespace cli {
 namespace fs = std::filesystem;
@@ -579,117 +580,40 @@ inline std::vector<float> read_pfm(const fs::path& path, int& w, int& h) {
   return m;
 }
 
-// ---------------------------------------------------------------- PNG via zlib
-struct Png {
-  int w = 0, h = 0, channels = 0, bitdepth = 0;
-  std::vector<uint16_t> px;  // interleaved, file channel order (RGB[A] / gray), 8-bit widened as-is
-};
+// ---------------------------------------------------------------- raster input (image_codecs.h) + PNG output
+// cv::imread picks its decoder by the file's signature; so does codecs::decode (PNG, JPEG, TIFF, BMP, PNM)
+using Png = codecs::Raster;  // w, h, channels (file order R, G, B [, A]), bitdepth 8 / 16 (32 = float samples in f32), px
 inline uint32_t be32(const unsigned char* p) {
   return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3];
 }
-inline bool png_size(const fs::path& path, int& w, int& h) {
+inline std::string read_head(const fs::path& path, size_t n) {
   std::ifstream f(path, std::ios::binary);
-  unsigned char hd[24];
-  f.read(reinterpret_cast<char*>(hd), 24);
-  if (!f.good() || memcmp(hd, "\x89PNG\r\n\x1a\n", 8) != 0) {
+  std::string head(n, '\0');
+  f.read(&head[0], (std::streamsize)n);
+  head.resize((size_t)std::max<std::streamsize>(f.gcount(), 0));
+  return head;
+}
+inline bool raster_size(const fs::path& path, int& w, int& h) {
+  // the size sits in the first bytes for PNG / BMP / PNM, behind the metadata segments for JPEG, anywhere for TIFF
+  const std::string head = read_head(path, 4096);
+  if (codecs::probe_size(reinterpret_cast<const unsigned char*>(head.data()), head.size(), w, h)) {
+    return true;
+  }
+  if (head.size() < 4096) {
     return false;
   }
-  w = be32(hd + 16);
-  h = be32(hd + 20);
-  return true;
+  const std::string all = read_file(path.string());
+  return codecs::probe_size(reinterpret_cast<const unsigned char*>(all.data()), all.size(), w, h);
 }
-inline Png read_png(const fs::path& path) {
+inline Png read_raster(const fs::path& path) {
   const std::string data = read_file(path.string());
-  CHECK_MSG(data.size() > 8 && memcmp(data.data(), "\x89PNG\r\n\x1a\n", 8) == 0, "failed to load image: " + path.string());
-  const unsigned char* d = reinterpret_cast<const unsigned char*>(data.data());
-  size_t pos = 8;
-  std::string idat;
-  Png img;
-  int color_type = -1, interlace = 0;
-  while (pos + 12 <= data.size()) {
-    const uint32_t n = be32(d + pos);
-    const std::string tag(data, pos + 4, 4);
-    if (tag == "IHDR") {
-      img.w = be32(d + pos + 8);
-      img.h = be32(d + pos + 12);
-      img.bitdepth = d[pos + 16];
-      color_type = d[pos + 17];
-      interlace = d[pos + 20];
-    } else if (tag == "IDAT") {
-      idat.append(data, pos + 8, n);
-    } else if (tag == "IEND") {
-      break;
-    }
-    pos += 12 + n;
+  CHECK_MSG(!data.empty(), "failed to load image: " + path.string());
+  try {
+    return codecs::decode(reinterpret_cast<const unsigned char*>(data.data()), data.size());
+  } catch (const codecs::Error& e) {
+    LOG_FATAL("failed to load image: " + path.string() + " (" + e.what() + ")");
   }
-  CHECK_MSG(!interlace && (img.bitdepth == 8 || img.bitdepth == 16) && (color_type == 0 || color_type == 2 || color_type == 6),
-            "unsupported PNG flavour: " + path.string());
-  img.channels = color_type == 0 ? 1 : color_type == 2 ? 3 : 4;
-  const int bpp = img.channels * img.bitdepth / 8;
-  const size_t stride = (size_t)img.w * bpp;
-  std::vector<unsigned char> raw((stride + 1) * img.h);
-  uLongf rawLen = raw.size();
-  CHECK_MSG(uncompress(raw.data(), &rawLen, reinterpret_cast<const Bytef*>(idat.data()), idat.size()) == Z_OK &&
-                rawLen == raw.size(),
-            "corrupt PNG: " + path.string());
-  std::vector<unsigned char> cur(stride), prev(stride, 0);
-  img.px.resize((size_t)img.w * img.h * img.channels);
-  for (int y = 0; y < img.h; ++y) {
-    const unsigned char* line = raw.data() + (stride + 1) * y;
-    const unsigned char* in = line + 1;
-    const size_t B = (size_t)bpp;
-    switch (line[0]) {  // one tight loop per PNG filter type
-      case 0:
-        memcpy(cur.data(), in, stride);
-        break;
-      case 1:
-        for (size_t i = 0; i < B && i < stride; ++i) {
-          cur[i] = in[i];
-        }
-        for (size_t i = B; i < stride; ++i) {
-          cur[i] = (unsigned char)(in[i] + cur[i - B]);
-        }
-        break;
-      case 2:
-        for (size_t i = 0; i < stride; ++i) {
-          cur[i] = (unsigned char)(in[i] + prev[i]);
-        }
-        break;
-      case 3:
-        for (size_t i = 0; i < B && i < stride; ++i) {
-          cur[i] = (unsigned char)(in[i] + (prev[i] >> 1));
-        }
-        for (size_t i = B; i < stride; ++i) {
-          cur[i] = (unsigned char)(in[i] + ((cur[i - B] + prev[i]) >> 1));
-        }
-        break;
-      case 4:
-        for (size_t i = 0; i < B && i < stride; ++i) {
-          cur[i] = (unsigned char)(in[i] + prev[i]);
-        }
-        for (size_t i = B; i < stride; ++i) {
-          const int a = cur[i - B], b = prev[i], c = prev[i - B];
-          const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-          cur[i] = (unsigned char)(in[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
-        }
-        break;
-      default:
-        LOG_FATAL("bad PNG filter: " + path.string());
-    }
-    uint16_t* o = &img.px[(size_t)y * img.w * img.channels];
-    const int nv = img.w * img.channels;
-    if (img.bitdepth == 16) {
-      for (int i = 0; i < nv; ++i) {
-        o[i] = uint16_t((cur[2 * i] << 8) | cur[2 * i + 1]);
-      }
-    } else {
-      for (int i = 0; i < nv; ++i) {
-        o[i] = cur[i];
-      }
-    }
-    prev.swap(cur);
-  }
-  return img;
+  return Png();
 }
 inline void write_png(const fs::path& path, const uint16_t* px, int w, int h, int channels, int bitdepth) {
   const int bpp = channels * bitdepth / 8;
@@ -738,46 +662,45 @@ inline void write_png(const fs::path& path, const uint16_t* px, int w, int h, in
 
 // cv_util::loadImage<Vec3w> (CvUtil.h:196-284): IMREAD_UNCHANGED -> 16U (8-bit x257) -> BGR
 // into a caller buffer of expectW x expectH x 3 (pinned staging memory of the CLI's I/O pipeline)
-inline void load_color_bgr16_into(const fs::path& path, uint16_t* out, int expectW, int expectH) {
-  const Png p = read_png(path);
-  CHECK_MSG(p.w == expectW && p.h == expectH, "image size mismatch: " + path.string());
-  const int mul = p.bitdepth == 8 ? 257 : 1;
+inline void raster_to_bgr16(const Png& p, const fs::path& path, uint16_t* out) {
+  CHECK_MSG(p.bitdepth == 8 || p.bitdepth == 16, "cannot use a float image as colour: " + path.string());
+  const int mul = p.bitdepth == 8 ? 257 : 1;  // convertTo(CV_16U, 65535 / 255)
   const size_t n = (size_t)p.w * p.h;
   for (size_t i = 0; i < n; ++i) {
     if (p.channels == 1) {
-      out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = p.px[i] * mul;
-    } else {
+      out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = p.px[i] * mul;  // COLOR_GRAY2BGR
+    } else {                                                           // COLOR_BGRA2BGR drops the alpha
       out[3 * i + 0] = p.px[p.channels * i + 2] * mul;  // B
       out[3 * i + 1] = p.px[p.channels * i + 1] * mul;  // G
       out[3 * i + 2] = p.px[p.channels * i + 0] * mul;  // R
     }
   }
 }
+inline void load_color_bgr16_into(const fs::path& path, uint16_t* out, int expectW, int expectH) {
+  const Png p = read_raster(path);
+  CHECK_MSG(p.w == expectW && p.h == expectH, "image size mismatch: " + path.string());
+  raster_to_bgr16(p, path, out);
+}
 inline std::vector<uint16_t> load_color_bgr16(const fs::path& path, int& w, int& h) {
-  const Png p = read_png(path);
+  const Png p = read_raster(path);
   w = p.w;
   h = p.h;
   std::vector<uint16_t> out((size_t)w * h * 3);
-  const int mul = p.bitdepth == 8 ? 257 : 1;
-  for (size_t i = 0; i < (size_t)w * h; ++i) {
-    if (p.channels == 1) {
-      out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = p.px[i] * mul;
-    } else {
-      out[3 * i + 0] = p.px[p.channels * i + 2] * mul;  // B
-      out[3 * i + 1] = p.px[p.channels * i + 1] * mul;  // G
-      out[3 * i + 2] = p.px[p.channels * i + 0] * mul;  // R
-    }
-  }
+  raster_to_bgr16(p, path, out.data());
   return out;
 }
-// cv_util::loadImage<bool> (CvUtil.h:235-239): to 8-bit, threshold > 127 -> 1
+// cv_util::loadImage<bool> (CvUtil.h:226-262): to 8-bit, threshold > 127 -> 1 on every channel, then (3 / 4 channels)
+// COLOR_BGR[A]2GRAY of the 0 / 1 values — whose fixed-point weights (B 0.114, G 0.587, R 0.299, rounded) give 1 exactly
+// when the GREEN channel passed the threshold (G alone rounds to 1, B + R together to 0)
 inline std::vector<uint8_t> load_mask(const fs::path& path, int& w, int& h) {
-  const Png p = read_png(path);
+  const Png p = read_raster(path);
+  CHECK_MSG(p.bitdepth == 8 || p.bitdepth == 16, "cannot use a float image as a mask: " + path.string());
   w = p.w;
   h = p.h;
   std::vector<uint8_t> out((size_t)w * h);
+  const int pick = p.channels >= 3 ? 1 : 0;
   for (size_t i = 0; i < out.size(); ++i) {
-    unsigned v = p.px[(size_t)p.channels * i];
+    unsigned v = p.px[(size_t)p.channels * i + pick];
     if (p.bitdepth == 16) {
       v = (unsigned)lrintf(v * (255.0f / 65535.0f));  // convertTo(CV_8U, 255/65535): saturate_cast rounds
     }
@@ -928,18 +851,27 @@ inline std::vector<float> load_float(const fs::path& path, int& w, int& h) {
   if (path.extension() == ".exr") {
     return read_exr_f32(path, w, h);
   }
-  const Png p = read_png(path);
+  const Png p = read_raster(path);
   w = p.w;
   h = p.h;
+  if (p.bitdepth == 32) {  // a float TIFF: convertTo(CV_32F) of CV_32F is a copy
+    return p.f32;
+  }
   std::vector<float> out((size_t)w * h);
   const float scale = 1.0f / (p.bitdepth == 16 ? 65535.0f : 255.0f);
   for (size_t i = 0; i < out.size(); ++i) {
-    out[i] = p.px[(size_t)p.channels * i] * scale;
+    if (p.channels == 1) {
+      out[i] = p.px[i] * scale;
+    } else {  // COLOR_BGR[A]2GRAY on the scaled floats (order of the float operations as OpenCV's scalar code; unpinned)
+      const float r = p.px[(size_t)p.channels * i] * scale, g = p.px[(size_t)p.channels * i + 1] * scale,
+                  b = p.px[(size_t)p.channels * i + 2] * scale;
+      out[i] = b * 0.114f + g * 0.587f + r * 0.299f;
+    }
   }
   return out;
 }
 inline bool image_size(const fs::path& path, int& w, int& h) {
-  return path.extension() == ".pfm" ? pfm_size(path, w, h) : path.extension() == ".exr" ? exr_size(path, w, h) : png_size(path, w, h);
+  return path.extension() == ".pfm" ? pfm_size(path, w, h) : path.extension() == ".exr" ? exr_size(path, w, h) : raster_size(path, w, h);
 }
 // ---------------------------------------------------------------- OpenEXR (output)
 // What cv::imwrite(".exr", CV_32FC1) leaves behind for --output_formats=exr (PyramidLevel.h:515-516,

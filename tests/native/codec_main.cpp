@@ -1,0 +1,34 @@
+// Test harness (CPU only) for cli/image_codecs.h. usage: codec_main <image file> [<raw output>]
+// Prints "<kind> <w> <h> <channels> <bitdepth> <probe_w> <probe_h>" and writes the samples (uint16 little-endian,
+// file channel order; float32 for bitdepth 32) to <raw output>. A file the decoder refuses: prints "error: <why>", exit 3.
+#include <cstdio>
+#include <fstream>
+#include <iterator>
+
+#include "../../facebook360_dep_amd/cli/image_codecs.h"
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    return 2;
+  }
+  std::ifstream f(argv[1], std::ios::binary);
+  const std::vector<unsigned char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  try {
+    const codecs::Raster r = codecs::decode(data.data(), data.size());
+    int pw = -1, ph = -1;
+    codecs::probe_size(data.data(), data.size(), pw, ph);
+    printf("%s %d %d %d %d %d %d\n", codecs::sniff(codecs::Bytes{data.data(), data.size()}), r.w, r.h, r.channels, r.bitdepth, pw, ph);
+    if (argc > 2) {
+      std::ofstream o(argv[2], std::ios::binary);
+      if (r.bitdepth == 32) {
+        o.write(reinterpret_cast<const char*>(r.f32.data()), (std::streamsize)(r.f32.size() * 4));
+      } else {
+        o.write(reinterpret_cast<const char*>(r.px.data()), (std::streamsize)(r.px.size() * 2));
+      }
+    }
+  } catch (const codecs::Error& e) {
+    printf("error: %s\n", e.what());
+    return 3;
+  }
+  return 0;
+}

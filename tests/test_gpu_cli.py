@@ -74,6 +74,74 @@ def test_derp_cli_layout_and_values(dataset, tmp_path):
     assert np.array_equal(np.frombuffer(raw[len(header):], dtype="<f4").reshape(h0, w0), pfm, equal_nan=True)
 
 
+def _converted_copy(src_root, dst_root, frames, colour, mask=None):
+    """The dataset of `src_root` with every colour (and mask) PNG of `frames` re-encoded by colour(array, path_without_ext)
+    / mask(...), which write the file under whatever extension they like."""
+    import shutil
+
+    from facebook360_dep_amd import imageio as dio
+
+    shutil.copytree(src_root, dst_root)
+    for kind, fn in (("color_levels", colour), ("foreground_masks_levels", mask)):
+        base = os.path.join(dst_root, "video", kind)
+        if fn is None or not os.path.isdir(base):
+            continue
+        for level in os.listdir(base):
+            for cam in os.listdir(os.path.join(base, level)):
+                for name in os.listdir(os.path.join(base, level, cam)):
+                    path = os.path.join(base, level, cam, name)
+                    if name[:-4] in frames:
+                        fn(dio.read_png(path), path[:-4])
+                    os.remove(path)
+
+
+def test_derp_cli_reads_tiff_pnm_and_jpeg_inputs(dataset, tmp_path):
+    """cv::imread takes whatever the colour / mask directories hold (CvUtil.cpp:23-29; the extension only names the
+    file, ImageUtil.h:48-56). Lossless re-encodings of the inputs (16-bit tiled big-endian LZW TIFF with a predictor,
+    PGM masks) must give byte-identical disparities; a JPEG data set must give what a PNG data set holding libjpeg's
+    decode of the same files gives."""
+    from tests.test_image_codecs import tiff_bytes
+
+    flags = ["--first=000000", "--last=000000", "--partial_coverage", "--resolution=96", "--use_foreground_masks"]
+
+    def level0(out):
+        return {cam: open(os.path.join(out, "disparity_levels", "level_0", cam, "000000.pfm"), "rb").read()
+                for cam in sorted(os.listdir(os.path.join(out, "disparity_levels", "level_0")))}
+
+    run("DerpCLI", "--input_root=" + dataset["root"], "--output_root=" + str(tmp_path / "out_png"), *flags)
+    want = level0(str(tmp_path / "out_png"))
+    assert len(want) == dataset["n"]
+
+    def tif(a, stem):  # imageio.read_png returns the reference's channel order (B, G, R): the file holds R, G, B
+        open(stem + ".tif", "wb").write(tiff_bytes(np.ascontiguousarray(a[..., ::-1]), ">", 5, 2, (16, 16)))
+
+    def pgm(a, stem):
+        open(stem + ".pgm", "wb").write(b"P5\n%d %d\n255\n" % (a.shape[1], a.shape[0]) + a.astype(np.uint8).tobytes())
+
+    _converted_copy(dataset["root"], str(tmp_path / "in_tif"), ["000000"], tif, pgm)
+    run("DerpCLI", "--input_root=" + str(tmp_path / "in_tif"), "--output_root=" + str(tmp_path / "out_tif"), *flags)
+    assert level0(str(tmp_path / "out_tif")) == want
+
+    Image = pytest.importorskip("PIL.Image")
+    from facebook360_dep_amd import imageio as dio
+
+    def jpg(a, stem):
+        Image.fromarray((a[..., ::-1] >> 8).astype(np.uint8)).save(stem + ".jpg", quality=92, subsampling=2)
+
+    def png_of_jpg(a, stem):
+        jpg(a, stem)
+        decoded = np.asarray(Image.open(stem + ".jpg"))
+        os.remove(stem + ".jpg")
+        dio.write_png8(stem + ".png", decoded[..., ::-1])
+
+    _converted_copy(dataset["root"], str(tmp_path / "in_jpg"), ["000000"], jpg)
+    _converted_copy(dataset["root"], str(tmp_path / "in_jpg_as_png"), ["000000"], png_of_jpg)
+    run("DerpCLI", "--input_root=" + str(tmp_path / "in_jpg"), "--output_root=" + str(tmp_path / "out_jpg"), *flags)
+    run("DerpCLI", "--input_root=" + str(tmp_path / "in_jpg_as_png"), "--output_root=" + str(tmp_path / "out_jpg_as_png"), *flags)
+    got = level0(str(tmp_path / "out_jpg"))
+    assert got == level0(str(tmp_path / "out_jpg_as_png")) and got != want
+
+
 def test_derp_cli_resume_and_camera_subset(dataset, tmp_path):
     """Checkpoint / resume through the per-level PFMs (DerpCLI.cpp:153-155,276-303) and --cameras."""
     from facebook360_dep_amd import imageio as dio
