@@ -575,6 +575,13 @@ inline std::vector<float> read_pfm(const fs::path& path, int& w, int& h) {
   f >> w >> h >> endian;
   CHECK_MSG(endian <= 0.0, "only little endian .pfm files supported: " + path.string());
   f.ignore();
+  // the header is text from a file: no allocation before it is known to describe what the file holds
+  CHECK_MSG(f.good() && w > 0 && h > 0 && w <= (1 << 20) && h <= (1 << 20), "bad .pfm header: " + path.string());
+  const std::streamoff at = f.tellg();
+  f.seekg(0, std::ios::end);
+  const std::streamoff left = f.tellg() - at;
+  f.seekg(at);
+  CHECK_MSG(left >= (std::streamoff)((size_t)w * h * sizeof(float)), "truncated .pfm file: " + path.string());
   std::vector<float> m((size_t)w * h);
   f.read(reinterpret_cast<char*>(m.data()), m.size() * sizeof(float));
   return m;

@@ -44,6 +44,14 @@ struct Bytes {
   size_t n;
   void span(size_t off, size_t len, const char* what) const { need(off <= n && len <= n - off, what); }
 };
+// OpenCV's own limits (CV_IO_MAX_IMAGE_WIDTH / _HEIGHT 2^20, CV_IO_MAX_IMAGE_PIXELS 2^30), and a plausibility bound
+// every decoder applies before it allocates: a header may not promise more samples than `perByte` per byte of
+// compressed data can deliver (deflate expands at most 1032 : 1, a TIFF LZW code at most 4 KB, a JPEG block needs at
+// least two bits) — a corrupt or hostile header fails with a message instead of with an out-of-memory abort.
+inline void plausible(int64_t w, int64_t h, size_t bytesPromised, size_t bytesPresent, size_t perByte) {
+  need(w > 0 && h > 0 && w <= (1 << 20) && h <= (1 << 20) && w * h <= ((int64_t)1 << 30), "image size outside 1 .. 2^20 x 2^20, 2^30 pixels");
+  need(bytesPromised / perByte <= bytesPresent + 1024, "corrupt image: the header promises more data than the file can hold");
+}
 
 inline uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
 inline uint32_t be16(const unsigned char* p) { return (uint32_t(p[0]) << 8) | p[1]; }
@@ -126,6 +134,7 @@ inline Raster decode_png(const Bytes& b) {
       total += (size_t)ph * (1 + ((size_t)pw * bitsPerPixel + 7) / 8);
     }
   }
+  plausible(W, H, total, idat.size(), 1032);
   const std::vector<unsigned char> raw = inflate_all(idat.data(), idat.size(), total, "corrupt PNG (inflate)");
 
   const bool palette = ct == 3;
@@ -286,6 +295,7 @@ struct JpegHuff {
     for (int len = 1; len <= 16; ++len) {
       valptr[len] = k;
       mincode[len] = code;
+      need(code + counts[len - 1] <= (1 << len), "corrupt JPEG Huffman table (over-subscribed)");
       for (int i = 0; i < counts[len - 1]; ++i, ++k, ++code) {
         if (len <= 9) {
           const int first = code << (9 - len);
@@ -559,6 +569,7 @@ inline Raster decode_jpeg(const Bytes& b) {
         if (nc == 1) {  // a single-component frame is never interleaved: its sampling factors do not matter
           comps[0].h = comps[0].v = hmax = vmax = 1;
         }
+        plausible(W, H, (size_t)W * H, b.n, 8 * 64 / 2);
         const int mcusX = (W + 8 * hmax - 1) / (8 * hmax), mcusY = (H + 8 * vmax - 1) / (8 * vmax);
         for (auto& c : comps) {
           c.blocksW = mcusX * c.h;
@@ -1023,7 +1034,7 @@ inline Raster decode_tiff(const Bytes& b) {
   TiffFile f{b};
   need(f.open(), "not a TIFF file");
   const int W = (int)f.get(256, 0), H = (int)f.get(257, 0);
-  need(W > 0 && H > 0, "TIFF without ImageWidth / ImageLength");
+  need(W > 0 && H > 0 && W <= (1 << 20) && H <= (1 << 20), "TIFF ImageWidth / ImageLength outside 1 .. 2^20");
   const int spp = (int)f.get(277, 1), bits = (int)f.get(258, 1), compression = (int)f.get(259, 1), photometric = (int)f.get(262, 1);
   const int planar = (int)f.get(284, 1), predictor = (int)f.get(317, 1), format = (int)f.get(339, 1), fill = (int)f.get(266, 1);
   const int orientation = (int)f.get(274, 1);
@@ -1045,14 +1056,23 @@ inline Raster decode_tiff(const Bytes& b) {
   need(spp != 2, "unsupported TIFF: gray + alpha");
   const bool tiled = f.find(322) != nullptr;
   const int tw = tiled ? (int)f.get(322, 0) : W, th = tiled ? (int)f.get(323, 0) : (int)std::min<uint32_t>(f.get(278, (uint32_t)H), (uint32_t)H);
-  need(tw > 0 && th > 0, "corrupt TIFF tile / strip size");
+  need(tw > 0 && th > 0 && tw <= (1 << 20) && th <= (1 << 20), "corrupt TIFF tile / strip size");
   const TiffEntry* offs = f.find(tiled ? 324 : 273);
   const TiffEntry* counts = f.find(tiled ? 325 : 279);
   need(offs && counts, "TIFF without strip / tile offsets");
   const int across = (W + tw - 1) / tw, down = (H + th - 1) / th;
   const int planes = planar == 2 ? spp : 1, chunkSpp = planar == 2 ? 1 : spp;
-  need(offs->count >= (uint32_t)(across * down * planes) && counts->count >= offs->count, "TIFF with too few strips / tiles");
+  need((int64_t)across * down * planes <= (int64_t)offs->count && counts->count >= offs->count, "TIFF with too few strips / tiles");
   const int bytesPer = bits / 8;
+  {
+    size_t present = 0;
+    for (uint32_t i = 0; i < (uint32_t)(across * down * planes); ++i) {
+      present += f.value(*counts, i);
+    }
+    need(present <= b.n, "TIFF strips / tiles larger than the file");
+    plausible(W, H, (size_t)W * H * spp * bytesPer, present, compression == 1 ? 1 : 4096);
+    need((int64_t)tw * th <= ((int64_t)1 << 30) && (size_t)tw * th * spp * bytesPer / 4096 <= b.n + 1024, "corrupt TIFF tile / strip size");
+  }
 
   // samples as stored, interleaved, native order
   std::vector<uint16_t> px;
@@ -1212,6 +1232,7 @@ inline Raster decode_bmp(const Bytes& b) {
   need((info.bpp == 8 || info.bpp == 24 || info.bpp == 32) && (info.compression == 0 || (info.compression == 3 && info.bpp == 32)),
        "unsupported BMP flavour (8-bit palette, 24-bit, 32-bit uncompressed only)");
   const size_t stride = (((size_t)info.w * info.bpp + 31) / 32) * 4;
+  plausible(info.w, info.h, stride * info.h, b.n, 1);
   b.span(info.dataOffset, stride * info.h, "truncated BMP file");
   Raster img;
   img.w = info.w;
@@ -1304,6 +1325,7 @@ inline Raster decode_pnm(const Bytes& b) {
   img.channels = (info.kind == 3 || info.kind == 6) ? 3 : 1;
   img.bitdepth = info.maxval < 256 ? 8 : 16;
   const size_t nv = (size_t)info.w * info.h * img.channels;
+  plausible(info.w, info.h, info.kind == 4 ? nv / 8 : info.kind == 1 ? nv : info.kind >= 5 ? nv * (img.bitdepth / 8) : nv * 2, b.n - info.data, 1);
   img.px.resize(nv);
   if (info.kind == 4) {
     const size_t stride = ((size_t)info.w + 7) / 8;

@@ -90,9 +90,10 @@ def _converted_copy(src_root, dst_root, frames, colour, mask=None):
             for cam in os.listdir(os.path.join(base, level)):
                 for name in os.listdir(os.path.join(base, level, cam)):
                     path = os.path.join(base, level, cam, name)
-                    if name[:-4] in frames:
-                        fn(dio.read_png(path), path[:-4])
-                    os.remove(path)
+                    a = dio.read_png(path) if name[:-4] in frames else None
+                    os.remove(path)  # first: fn may write a .png of its own under the same name
+                    if a is not None:
+                        fn(a, path[:-4])
 
 
 def test_derp_cli_reads_tiff_pnm_and_jpeg_inputs(dataset, tmp_path):

