@@ -179,6 +179,63 @@ def read_png(path):
     return np.ascontiguousarray(arr[..., 0] if ch == 1 else arr)
 
 
+def read_image(path):
+    """What cv2.imread(path, cv2.IMREAD_UNCHANGED) returns (scripts/render/resize.py:66-70) for a PNG / JPEG / TIFF /
+    BMP / PNM file — uint8 / uint16 / float32, [h, w] or [h, w, 3|4] in B, G, R [, A] order — decoded by the C-ABI's
+    derp_image_decode (cli/image_codecs.h; the decoder is chosen by the file's signature, JPEG samples are
+    libjpeg-turbo's integers). Raises ValueError with the decoder's message for anything it refuses."""
+    import ctypes as C
+
+    from . import derp
+
+    lib = derp.lib()
+    lib.derp_image_last_error.restype = C.c_char_p
+    with open(path, "rb") as f:
+        data = f.read()
+    w, h, ch, bd = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    if lib.derp_image_info(data, C.c_size_t(len(data)), C.byref(w), C.byref(h), C.byref(ch), C.byref(bd)):
+        raise ValueError("failed to load image: %s (%s)" % (path, lib.derp_image_last_error().decode()))
+    out = np.empty((h.value, w.value, ch.value), dtype=np.float32 if bd.value == 32 else np.uint16)
+    if lib.derp_image_decode(data, C.c_size_t(len(data)), out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes)):
+        raise ValueError("failed to load image: %s (%s)" % (path, lib.derp_image_last_error().decode()))
+    if bd.value == 8:
+        out = out.astype(np.uint8)
+    return np.ascontiguousarray(out[..., 0] if ch.value == 1 else out)
+
+
+def write_tiff(path, arr):
+    """A baseline little-endian TIFF, one Deflate-compressed strip: uint8 / uint16 [h, w] or [h, w, 3|4] in B, G, R [, A]
+    order (stored R, G, B [, A]; a fourth sample is declared as un-associated alpha), float32 [h, w]. Lossless, so
+    which TIFF flavour cv2.imwrite would have picked (LZW) does not matter to a reader."""
+    a = np.asarray(arr)
+    if a.ndim == 2:
+        a = a[..., None]
+    h, w, spp = a.shape
+    if spp >= 3:
+        a = a[..., [2, 1, 0] + ([3] if spp == 4 else [])]
+    fmt = 3 if a.dtype == np.float32 else 1
+    bits = a.dtype.itemsize * 8
+    strip = zlib.compress(np.ascontiguousarray(a).astype(a.dtype.newbyteorder("<")).tobytes(), 6)
+    tags = [(256, 4, [w]), (257, 4, [h]), (258, 3, [bits] * spp), (259, 3, [8]), (262, 3, [2 if spp >= 3 else 1]), (273, 4, [8]),
+            (277, 3, [spp]), (278, 4, [h]), (279, 4, [len(strip)]), (284, 3, [1]), (339, 3, [fmt] * spp)]
+    if spp == 4:
+        tags.append((338, 3, [2]))
+    tags.sort()
+    body = strip + (b"\0" if len(strip) & 1 else b"")
+    ifd_at = 8 + len(body)
+    extra_at = ifd_at + 2 + 12 * len(tags) + 4
+    ifd, extra = struct.pack("<H", len(tags)), b""
+    for tag, typ, vals in tags:
+        blob = struct.pack("<" + {3: "H", 4: "I"}[typ] * len(vals), *vals)
+        if len(blob) <= 4:
+            ifd += struct.pack("<HHI", tag, typ, len(vals)) + blob.ljust(4, b"\0")
+        else:
+            ifd += struct.pack("<HHII", tag, typ, len(vals), extra_at + len(extra))
+            extra += blob + (b"\0" if len(blob) & 1 else b"")
+    with open(path, "wb") as f:
+        f.write(b"II" + struct.pack("<HI", 42, ifd_at) + body + ifd + struct.pack("<I", 0) + extra)
+
+
 def load_color_u16(path):
     """cv_util::loadImage<Vec3w> (CvUtil.h:196-284): depth -> 16U (x257 from 8-bit), channels -> BGR."""
     a = read_png(path)

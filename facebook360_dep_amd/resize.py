@@ -45,9 +45,15 @@ def resize_camera(g, src_dir, dst_dir, camera, rig_resolution, frame, threshold)
         raise Exception(f"Non-existent file for resize: {original_file}")
     frame_fn = os.path.basename(original_file)
     ext = os.path.splitext(frame_fn)[1]
-    img = imageio.read_pfm(original_file) if ext == ".pfm" else imageio.read_png(original_file)
+    # cv2.imread(original_file, cv2.IMREAD_UNCHANGED): whatever format the directory holds (resize.py:66-70)
+    img = imageio.read_pfm(original_file) if ext == ".pfm" else imageio.read_image(original_file)
     if img.ndim == 3 and img.shape[2] == 4:
         img = img[..., :3]
+    # cv2.imwrite(new_file, scaled) keeps the source's container. PNG and TIFF stay what they are; a lossy or exotic
+    # source (JPEG, BMP, PNM) is written as PNG under a .png name — the level files then hold exactly the resized
+    # samples instead of a second generation of JPEG loss (the one deliberate difference from resize.py:82-85).
+    out_ext = ext if ext.lower() in (".pfm", ".png", ".tif", ".tiff") else ".png"
+    frame_fn = os.path.splitext(frame_fn)[0] + out_ext
     for level, (width, height) in enumerate(level_sizes(rig_resolution[0], rig_resolution[1])):
         new_file = os.path.join(dst_dir, f"level_{level}", camera, frame_fn)
         os.makedirs(os.path.dirname(new_file), exist_ok=True)
@@ -63,6 +69,8 @@ def resize_camera(g, src_dir, dst_dir, camera, rig_resolution, frame, threshold)
             scaled = np.where(scaled > threshold, 255, 0).astype(scaled.dtype)  # cv2.threshold(.., 255, THRESH_BINARY)
         if ext == ".pfm":
             imageio.write_pfm(new_file, scaled)
+        elif out_ext.lower() in (".tif", ".tiff"):
+            imageio.write_tiff(new_file, scaled)
         elif scaled.dtype == np.uint16:
             imageio.write_png16(new_file, scaled)
         else:

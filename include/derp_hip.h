@@ -128,6 +128,16 @@ int derp_build_pyramid_background_disparity(derp_ctx* ctx, int dst, const float*
 int derp_download_level_color(derp_ctx* ctx, int level, int src, uint16_t* bgr);
 int derp_download_level_mask(derp_ctx* ctx, int level, int src, uint8_t* mask01);
 int derp_download_level_background(derp_ctx* ctx, int level, int dst, float* disp);
+/* ---- raster inputs (host only; facebook360_dep_amd/csrc/derp_images.cpp over cli/image_codecs.h) ------------------
+ * What `cv::imread(path, cv::IMREAD_UNCHANGED)` returns (CvUtil.cpp:23-29; scripts/render/resize.py:66-70) for the bytes
+ * of a PNG / JPEG / TIFF / BMP / PNM file, the decoder chosen by signature: derp_image_info gives the geometry
+ * (channels 1 / 3 / 4; bitdepth 8, 16 or 32 = float), derp_image_decode fills `out` with w * h * channels samples in
+ * OpenCV's order (B, G, R [, A]) — uint16 for bitdepth 8 (widened, not scaled) and 16, float for 32. 0 / non-zero;
+ * derp_image_last_error() holds the reason ("unsupported JPEG colour space (CMYK / YCCK)", ...), per thread. */
+int derp_image_info(const void* bytes, size_t n, int* w, int* h, int* channels, int* bitdepth);
+int derp_image_decode(const void* bytes, size_t n, void* out, size_t out_bytes);
+const char* derp_image_last_error(void);
+
 /* one image: kind 0 = BGR u16 x3, 1 = u8 x1, 2 = f32 x1, 3 = BGR f32 x3 (cv_util::resizeImage<Vec3f>,
  * CvUtil.h:139-147 — the colour guide of UpsampleDisparity.cpp:117). Shrinking only. */
 int derp_resize_area(derp_ctx* ctx, int kind, const void* src, int w, int h, void* dst, int dw, int dh);

@@ -562,6 +562,37 @@ def test_resize_module_builds_level_directories(dataset, tmp_path):
         for cam in imgs:
             got = dio.read_png(str(dst / ("level_%d" % level) / cam / "000000.png"))
             assert np.array_equal(got, O.cv_resize_area(imgs[cam], widths[level], widths[level])), (level, cam)
+    # sources in other containers (resize.py reads them with cv2.imread): 16-bit TIFF stays TIFF, level for level the
+    # same samples as from the PNG; 8-bit JPEG comes out as PNG holding the resized libjpeg decode
+    from tests.test_image_codecs import tiff_bytes
+
+    cam = rig["cameras"][0]["id"]
+    src2, dst2 = tmp_path / "color_tif", tmp_path / "levels_tif"
+    for c in rig["cameras"]:
+        os.makedirs(src2 / c["id"])
+        open(str(src2 / c["id"] / "000000.tif"), "wb").write(tiff_bytes(np.ascontiguousarray(imgs[c["id"]][..., ::-1]), ">", 5, 2))
+    p = subprocess.run([sys.executable, "-m", "facebook360_dep_amd.resize", "--src_dir", str(src2), "--dst_dir", str(dst2),
+                        "--rig", str(rigf)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for level in (2, 4, 9):
+        got = dio.read_image(str(dst2 / ("level_%d" % level) / cam / "000000.tif"))
+        assert np.array_equal(got, dio.read_png(str(dst / ("level_%d" % level) / cam / "000000.png"))), level
+    Image = pytest.importorskip("PIL.Image")
+    src3, dst3 = tmp_path / "color_jpg", tmp_path / "levels_jpg"
+    smooth = {}
+    for c in rig["cameras"]:
+        os.makedirs(src3 / c["id"])
+        y, x = np.mgrid[0:512, 0:512]
+        rgb = np.stack([(np.sin(x / 40.0 + k) * 0.5 + 0.5) * 200 + np.cos(y / 30.0) * 40 for k in range(3)], -1).clip(0, 255).astype(np.uint8)
+        Image.fromarray(rgb).save(str(src3 / c["id"] / "000000.jpg"), quality=90)
+        smooth[c["id"]] = np.asarray(Image.open(str(src3 / c["id"] / "000000.jpg")))[..., ::-1]
+    p = subprocess.run([sys.executable, "-m", "facebook360_dep_amd.resize", "--src_dir", str(src3), "--dst_dir", str(dst3),
+                        "--rig", str(rigf)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    for level in (2, 4, 9):
+        got = dio.read_png(str(dst3 / ("level_%d" % level) / cam / "000000.png"))
+        want = O.cv_resize_area(smooth[cam].astype(np.uint16), widths[level], widths[level]).astype(np.uint8)
+        assert got.dtype == np.uint8 and np.array_equal(got, want), level
 
 
 def test_generate_foreground_masks_cli(dataset, tmp_path):

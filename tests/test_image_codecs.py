@@ -596,3 +596,35 @@ def test_hostile_headers_are_refused_before_anything_is_allocated(harness, tmp_p
         got, why, _ = decode(harness, path)
         assert got is None and why.startswith("error:"), (name, why)
         assert time.time() - t0 < 2.0, name
+
+
+def test_python_host_reads_the_same_through_the_c_abi(tmp_path):
+    """facebook360_dep_amd.imageio.read_image = derp_image_info + derp_image_decode of libderp_hip.so (what the pyramid
+    builder's cv2.imread stand-in uses): the committed JPEG vectors again, in OpenCV's channel order, and the TIFF writer
+    of the pyramid builder read back (and read by libtiff through Pillow)."""
+    from facebook360_dep_amd import imageio as dio
+
+    expected = json.load(open(os.path.join(GOLDEN, "expected.json")))
+    for name, e in sorted(expected.items()):
+        a = dio.read_image(os.path.join(GOLDEN, name))
+        assert a.dtype == np.uint8 and list(a.shape) == (e["shape"] if e["shape"][2] == 3 else e["shape"][:2])
+        rgb = a[..., ::-1] if a.ndim == 3 else a
+        assert zlib.crc32(np.ascontiguousarray(rgb).tobytes()) == e["crc32"], name
+    path = str(tmp_path / "t.tif")
+    for a in (scene(31, 17, 3, maxv=65535), scene(31, 17, 3), scene(31, 17, 1)[..., 0], scene(31, 17, 4),
+              np.random.default_rng(4).normal(0, 1, (17, 31)).astype(np.float32)):
+        dio.write_tiff(path, a)
+        back = dio.read_image(path)
+        assert back.dtype == a.dtype and back.shape == a.shape
+        if a.ndim == 3 and a.shape[2] == 4:  # un-associated alpha of an 8-bit file is multiplied in (libtiff's RGBA interface)
+            want = a.astype(np.int64)
+            want[..., :3] = (want[..., 3:] * want[..., :3] + 127) // 255
+            assert np.array_equal(back, want)
+        else:
+            assert np.array_equal(back, a)
+        if Image is not None and a.dtype == np.uint8 and a.ndim == 3:
+            ref = np.asarray(Image.open(path))
+            assert np.array_equal(ref, a[..., [2, 1, 0] + ([3] if a.shape[2] == 4 else [])])
+    open(path, "wb").write(b"RIFF\x10\0\0\0WEBPVP8 ")
+    with pytest.raises(ValueError, match="webp"):
+        dio.read_image(path)
