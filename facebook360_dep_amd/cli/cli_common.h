@@ -419,11 +419,19 @@ struct JsonParser {
   }
 };
 
-inline std::string read_file(const std::string& path) {
-  std::ifstream f(path, std::ios::binary);
-  std::stringstream ss;
-  ss << f.rdbuf();
-  return ss.str();
+inline std::string read_file(const std::string& path) {  // "" when the file cannot be read
+  std::string out;
+  if (FILE* f = fopen(path.c_str(), "rb")) {
+    if (fseek(f, 0, SEEK_END) == 0) {
+      const long n = ftell(f);
+      if (n > 0 && fseek(f, 0, SEEK_SET) == 0) {
+        out.resize((size_t)n);
+        out.resize(fread(&out[0], 1, (size_t)n, f));
+      }
+    }
+    fclose(f);
+  }
+  return out;
 }
 
 // Camera::loadRig (Camera.cpp:244-258) -> the C-ABI's camera descriptions
@@ -684,6 +692,20 @@ inline void raster_to_bgr16(const Png& p, const fs::path& path, uint16_t* out) {
   }
 }
 inline void load_color_bgr16_into(const fs::path& path, uint16_t* out, int expectW, int expectH) {
+  const std::string data = read_file(path.string());
+  CHECK_MSG(!data.empty(), "failed to load image: " + path.string());
+  const codecs::Bytes bytes{reinterpret_cast<const unsigned char*>(data.data()), data.size()};
+  int w = 0, h = 0;
+  bool fast = false;
+  try {
+    fast = codecs::png_fast_bgr16(bytes, out, expectW, expectH, w, h);
+  } catch (const codecs::Error& e) {
+    LOG_FATAL("failed to load image: " + path.string() + " (" + e.what() + ")");
+  }
+  if (fast) {
+    CHECK_MSG(w == expectW && h == expectH, "image size mismatch: " + path.string());
+    return;
+  }
   const Png p = read_raster(path);
   CHECK_MSG(p.w == expectW && p.h == expectH, "image size mismatch: " + path.string());
   raster_to_bgr16(p, path, out);

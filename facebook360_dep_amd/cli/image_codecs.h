@@ -9,6 +9,7 @@
 // samples are the same integers — pinned against Pillow's libjpeg-turbo in tests/test_image_codecs.py.
 // Errors are exceptions (codecs::Error); cli_common.h turns them into the glog-style fatal line with the file name.
 #pragma once
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -16,6 +17,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -56,20 +58,73 @@ inline void plausible(int64_t w, int64_t h, size_t bytesPromised, size_t bytesPr
 inline uint32_t be32(const unsigned char* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
 inline uint32_t be16(const unsigned char* p) { return (uint32_t(p[0]) << 8) | p[1]; }
 
-inline std::vector<unsigned char> inflate_all(const unsigned char* src, size_t n, size_t expect, const char* what) {
-  std::vector<unsigned char> out(expect);
+// zlib streams are inflated by libdeflate when the system has it (libdeflate.so.0 — libtiff's own dependency on this
+// image; 1.7 x zlib's inflate on 16-bit camera PNGs, and PNG inflation is what DerpSequence's disk-to-disk time is
+// made of on a 16-CPU box), found with dlopen so that nothing links against it; zlib otherwise, and whenever libdeflate
+// objects to a stream (it insists on the exact size and a valid Adler-32; libpng / libtiff are more forgiving).
+// DERP_NO_LIBDEFLATE=1 forces zlib.
+struct LibDeflate {
+  void* (*alloc)() = nullptr;
+  int (*zlibDecompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
+  void (*release)(void*) = nullptr;
+  LibDeflate() {
+    const char* off = getenv("DERP_NO_LIBDEFLATE");
+    if (off && *off && *off != '0') {
+      return;
+    }
+    if (void* lib = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL)) {
+      alloc = reinterpret_cast<void* (*)()>(dlsym(lib, "libdeflate_alloc_decompressor"));
+      zlibDecompress = reinterpret_cast<int (*)(void*, const void*, size_t, void*, size_t, size_t*)>(dlsym(lib, "libdeflate_zlib_decompress"));
+      release = reinterpret_cast<void (*)(void*)>(dlsym(lib, "libdeflate_free_decompressor"));
+      if (!alloc || !zlibDecompress || !release) {
+        alloc = nullptr;
+      }
+    }
+  }
+  static const LibDeflate& get() {
+    static const LibDeflate one;
+    return one;
+  }
+};
+// inflates exactly `expect` bytes into `out` (caller-owned, uninitialised is fine)
+inline void inflate_into(const unsigned char* src, size_t n, unsigned char* out, size_t expect, const char* what) {
+  const LibDeflate& ld = LibDeflate::get();
+  if (ld.alloc) {
+    struct Holder {
+      void* d = nullptr;
+      void (*release)(void*) = nullptr;
+      ~Holder() {
+        if (d) {
+          release(d);
+        }
+      }
+    };
+    static thread_local Holder h;
+    if (!h.d) {
+      h.d = ld.alloc();
+      h.release = ld.release;
+    }
+    size_t got = 0;
+    if (h.d && ld.zlibDecompress(h.d, src, n, out, expect, &got) == 0 && got == expect) {
+      return;
+    }
+  }
   z_stream z;
   memset(&z, 0, sizeof z);
   need(inflateInit(&z) == Z_OK, what);
   z.next_in = const_cast<Bytef*>(src);
   z.avail_in = (uInt)n;
-  z.next_out = out.data();
+  z.next_out = out;
   z.avail_out = (uInt)expect;
   const int rc = inflate(&z, Z_FINISH);
   const size_t got = expect - z.avail_out;
   inflateEnd(&z);
   // libpng / libtiff accept a stream that fills the expected size even when trailing bytes follow
   need((rc == Z_STREAM_END || rc == Z_OK || rc == Z_BUF_ERROR) && got == expect, what);
+}
+inline std::vector<unsigned char> inflate_all(const unsigned char* src, size_t n, size_t expect, const char* what) {
+  std::vector<unsigned char> out(expect);
+  inflate_into(src, n, out.data(), expect, what);
   return out;
 }
 
@@ -265,6 +320,127 @@ inline Raster decode_png(const Bytes& b) {
     }
   }
   return img;
+}
+
+// The pipeline's own flavour — non-interlaced 8 / 16-bit gray, RGB or RGBA without tRNS, which is what resize.py's
+// cv2.imwrite leaves in color_levels/ — straight into the caller's interleaved B, G, R uint16 buffer (8-bit x 257 =
+// convertTo(CV_16U, 65535 / 255); gray replicated; alpha dropped: cv_util::loadImage<Vec3w>, CvUtil.h:226-262): rows are
+// unfiltered in place in the inflated buffer and converted once, no intermediate raster. false = not that flavour
+// (nothing written; use decode_png). `w` / `h` return the file's size; a mismatch with expectW / expectH (when
+// given, > 0) is reported by the caller.
+inline bool png_fast_bgr16(const Bytes& b, uint16_t* out, int expectW, int expectH, int& w, int& h) {
+  PngInfo info;
+  if (!png_header(b, info) || info.interlace || (info.depth != 8 && info.depth != 16) ||
+      (info.colorType != 0 && info.colorType != 2 && info.colorType != 6)) {
+    return false;
+  }
+  const unsigned char* idat = nullptr;
+  size_t idatLen = 0;
+  std::vector<unsigned char> joined;
+  int nIdat = 0;
+  size_t pos = 8;
+  while (pos + 12 <= b.n) {
+    const uint32_t len = be32(b.d + pos);
+    b.span(pos + 8, (size_t)len + 4, "truncated PNG chunk");
+    if (!memcmp(b.d + pos + 4, "IDAT", 4)) {
+      if (nIdat++ == 0) {
+        idat = b.d + pos + 8;
+        idatLen = len;
+      } else {
+        if (nIdat == 2) {
+          joined.assign(idat, idat + idatLen);
+        }
+        joined.insert(joined.end(), b.d + pos + 8, b.d + pos + 8 + len);
+      }
+    } else if (!memcmp(b.d + pos + 4, "tRNS", 4) && info.colorType == 2) {
+      return false;
+    } else if (!memcmp(b.d + pos + 4, "IEND", 4)) {
+      break;
+    }
+    pos += 12 + (size_t)len;
+  }
+  if (nIdat > 1) {
+    idat = joined.data();
+    idatLen = joined.size();
+  }
+  w = info.w;
+  h = info.h;
+  if ((expectW > 0 && w != expectW) || (expectH > 0 && h != expectH)) {
+    return true;  // the caller compares sizes before it looks at `out`
+  }
+  const int ch = info.colorType == 0 ? 1 : info.colorType == 2 ? 3 : 4, bytes = info.depth / 8;
+  const size_t B = (size_t)ch * bytes, stride = (size_t)w * B, total = (size_t)h * (stride + 1);
+  plausible(w, h, total, idatLen, 1032);
+  std::unique_ptr<unsigned char[]> raw(new unsigned char[total]);  // not value-initialised: inflate fills every byte
+  inflate_into(idat, idatLen, raw.get(), total, "corrupt PNG (inflate)");
+  const std::vector<unsigned char> zeros(stride, 0);
+  const unsigned char* prev = zeros.data();
+  for (int y = 0; y < h; ++y) {
+    unsigned char* line = raw.get() + (size_t)y * (stride + 1);
+    unsigned char* cur = line + 1;
+    switch (line[0]) {
+      case 0:
+        break;
+      case 1:
+        for (size_t i = B; i < stride; ++i) {
+          cur[i] = (unsigned char)(cur[i] + cur[i - B]);
+        }
+        break;
+      case 2:
+        for (size_t i = 0; i < stride; ++i) {
+          cur[i] = (unsigned char)(cur[i] + prev[i]);
+        }
+        break;
+      case 3:
+        for (size_t i = 0; i < B && i < stride; ++i) {
+          cur[i] = (unsigned char)(cur[i] + (prev[i] >> 1));
+        }
+        for (size_t i = B; i < stride; ++i) {
+          cur[i] = (unsigned char)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
+        }
+        break;
+      case 4:
+        for (size_t i = 0; i < B && i < stride; ++i) {
+          cur[i] = (unsigned char)(cur[i] + prev[i]);
+        }
+        for (size_t i = B; i < stride; ++i) {
+          const int a = cur[i - B], bb = prev[i], c = prev[i - B];
+          const int pp = a + bb - c, pa = abs(pp - a), pb = abs(pp - bb), pc = abs(pp - c);
+          cur[i] = (unsigned char)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? bb : c)));
+        }
+        break;
+      default:
+        throw Error("bad PNG filter type");
+    }
+    uint16_t* o = out + (size_t)y * w * 3;
+    if (bytes == 2) {
+      if (ch == 1) {
+        for (int x = 0; x < w; ++x) {
+          o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = (uint16_t)((cur[2 * x] << 8) | cur[2 * x + 1]);
+        }
+      } else {
+        for (int x = 0; x < w; ++x) {
+          const unsigned char* s = cur + (size_t)x * B;
+          o[3 * x] = (uint16_t)((s[4] << 8) | s[5]);
+          o[3 * x + 1] = (uint16_t)((s[2] << 8) | s[3]);
+          o[3 * x + 2] = (uint16_t)((s[0] << 8) | s[1]);
+        }
+      }
+    } else if (ch == 1) {
+      for (int x = 0; x < w; ++x) {
+        o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = (uint16_t)(cur[x] * 257);
+      }
+    } else {
+      for (int x = 0; x < w; ++x) {
+        const unsigned char* s = cur + (size_t)x * B;
+        o[3 * x] = (uint16_t)(s[2] * 257);
+        o[3 * x + 1] = (uint16_t)(s[1] * 257);
+        o[3 * x + 2] = (uint16_t)(s[0] * 257);
+      }
+    }
+    prev = cur;
+  }
+  return true;
 }
 
 // ================================================================================================ JPEG

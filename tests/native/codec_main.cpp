@@ -1,9 +1,10 @@
 // Test harness (CPU only) for cli/image_codecs.h. usage: codec_main <image file> [<raw output>]
 // Prints "<kind> <w> <h> <channels> <bitdepth> <probe_w> <probe_h>" and writes the samples (uint16 little-endian,
-// file channel order; float32 for bitdepth 32) to <raw output>. A file the decoder refuses: prints "error: <why>", exit 3.
+// file channel order; float32 for bitdepth 32) to <raw output>. With a third argument --bgr16: png_fast_bgr16 instead. A file the decoder refuses: prints "error: <why>", exit 3.
 #include <cstdio>
 #include <fstream>
 #include <iterator>
+#include <string>
 
 #include "../../facebook360_dep_amd/cli/image_codecs.h"
 
@@ -13,6 +14,28 @@ int main(int argc, char** argv) {
   }
   std::ifstream f(argv[1], std::ios::binary);
   const std::vector<unsigned char> data((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+  if (argc > 3 && std::string(argv[3]) == "--bgr16") {  // the executables' colour fast path: B, G, R uint16, or "notfast"
+    try {
+      codecs::PngInfo info;
+      if (!codecs::png_header(codecs::Bytes{data.data(), data.size()}, info)) {
+        printf("notfast\n");
+        return 0;
+      }
+      std::vector<uint16_t> out((size_t)info.w * info.h * 3, 0xabcd);
+      int w = 0, h = 0;
+      if (!codecs::png_fast_bgr16(codecs::Bytes{data.data(), data.size()}, out.data(), 0, 0, w, h)) {
+        printf("notfast\n");
+        return 0;
+      }
+      printf("fast %d %d\n", w, h);
+      std::ofstream o(argv[2], std::ios::binary);
+      o.write(reinterpret_cast<const char*>(out.data()), (std::streamsize)(out.size() * 2));
+      return 0;
+    } catch (const codecs::Error& e) {
+      printf("error: %s\n", e.what());
+      return 3;
+    }
+  }
   try {
     const codecs::Raster r = codecs::decode(data.data(), data.size());
     int pw = -1, ph = -1;

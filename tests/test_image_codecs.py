@@ -33,7 +33,7 @@ except ImportError:  # the committed vectors still run
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("codec") / "codec_main")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-o", exe,
-                           os.path.join(ROOT, "tests", "native", "codec_main.cpp"), "-lz"])
+                           os.path.join(ROOT, "tests", "native", "codec_main.cpp"), "-lz", "-ldl"])
     return exe
 
 
@@ -240,6 +240,16 @@ def test_png_every_colour_type_depth_and_filter(harness, tmp_path, interlace):
                 want = png_expected(a, ct, depth, palette, trns)
                 assert kind == "png" and bd == (16 if depth == 16 else 8)
                 assert got.shape == want.shape and np.array_equal(got, want), (w, h, ct, depth, interlace, trns)
+                # the executables' colour fast path takes exactly the flavours it says it takes, and gives what
+                # cv_util::loadImage<Vec3w> makes of the generic decode (x257 from 8 bits, gray replicated, alpha dropped)
+                p = subprocess.run([harness, path, path + ".bgr", "--bgr16"], capture_output=True, text=True)
+                takes = (not interlace) and depth >= 8 and ct in (0, 2, 6) and not (ct == 2 and trns)
+                assert p.stdout.split()[0] == ("fast" if takes else "notfast"), (p.stdout, ct, depth, interlace, trns)
+                if takes:
+                    bgr = np.fromfile(path + ".bgr", dtype=np.uint16).reshape(h, w, 3)
+                    full = want.astype(np.int64) * (257 if depth == 8 else 1)
+                    full = np.repeat(full, 3, axis=2) if full.shape[2] == 1 else full[..., :3]
+                    assert np.array_equal(bgr, full[..., ::-1]), (w, h, ct, depth)
                 if Image is not None and (w, h) == (37, 29) and depth <= 8 and trns is None:
                     # the encoder above is not the only witness: libpng (through Pillow) reads the same file
                     mode = {1: "L", 3: "RGB", 4: "RGBA"}[want.shape[-1]]

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def harness(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("rv") / "rendezvous_main")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-o", exe,
-                           os.path.join(ROOT, "tests", "native", "rendezvous_main.cpp"), "-lz"])
+                           os.path.join(ROOT, "tests", "native", "rendezvous_main.cpp"), "-lz", "-ldl"])
     return exe
 
 
