@@ -1042,7 +1042,7 @@ struct IoPool {
   std::deque<std::function<void()>> queue[3];
   std::mutex mu;
   std::condition_variable cvWork, cvIdle;
-  int busy = 0;
+  int busy = 0, express = 0;
   bool stop = false;
   // CPUs this process may actually use: the scheduler affinity mask and the cgroup CPU quota (a container that sees
   // 256 hardware threads may be allowed 16 CPUs' worth of time; 64 busy workers then throttle the thread that feeds
@@ -1083,23 +1083,37 @@ struct IoPool {
     // -1 = auto: one and a half workers per usable CPU (file reads / writes block), at most 64
     int n = threads < 0 ? usable_cpus() * 3 / 2 : threads;
     n = std::min(n, 64);
+    // Priorities do not pre-empt: with every worker inside a 0.1-s PNG inflation, a staging copy or a result file waits
+    // for the first of them to finish (measured: up to 60 ms "waited for a free download plane" per coarse level).
+    // Two workers of a large pool therefore never take class-2 jobs.
+    express = n >= 8 ? 2 : 0;
     for (int i = 0; i < n; ++i) {
-      workers.emplace_back([this] {
+      const bool expressOnly = i < express;
+      workers.emplace_back([this, expressOnly] {
         on_worker_thread() = true;
         // below the thread that feeds the GPU: a saturated host otherwise stretches its kernel launches
         (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), 10);
+        const int classes = expressOnly ? 2 : 3;
+        auto mine = [this, classes] {
+          for (int c = 0; c < classes; ++c) {
+            if (!queue[c].empty()) {
+              return true;
+            }
+          }
+          return false;
+        };
         for (;;) {
           std::function<void()> job;
           {
             std::unique_lock<std::mutex> lk(mu);
-            cvWork.wait(lk, [this] { return stop || pending_locked(); });
-            if (!pending_locked()) {
+            cvWork.wait(lk, [&] { return stop || mine(); });
+            if (!mine()) {
               return;
             }
-            for (auto& q : queue) {
-              if (!q.empty()) {
-                job = std::move(q.front());
-                q.pop_front();
+            for (int c = 0; c < classes; ++c) {
+              if (!queue[c].empty()) {
+                job = std::move(queue[c].front());
+                queue[c].pop_front();
                 break;
               }
             }
@@ -1125,7 +1139,11 @@ struct IoPool {
       std::lock_guard<std::mutex> lk(mu);
       queue[std::min(std::max(prio, 0), 2)].push_back(std::move(job));
     }
-    cvWork.notify_one();
+    if (express) {
+      cvWork.notify_all();  // notify_one could pick an express worker for a class-2 job, which would go back to sleep
+    } else {
+      cvWork.notify_one();
+    }
   }
   void wait_idle() {
     std::unique_lock<std::mutex> lk(mu);
