@@ -48,8 +48,8 @@ struct Bytes {
 };
 // OpenCV's own limits (CV_IO_MAX_IMAGE_WIDTH / _HEIGHT 2^20, CV_IO_MAX_IMAGE_PIXELS 2^30), and a plausibility bound
 // every decoder applies before it allocates: a header may not promise more samples than `perByte` per byte of
-// compressed data can deliver (deflate expands at most 1032 : 1, a TIFF LZW code at most 4 KB, a JPEG block needs at
-// least two bits) — a corrupt or hostile header fails with a message instead of with an out-of-memory abort.
+// compressed data can deliver (deflate expands at most 1032 : 1, a TIFF LZW code at most 4 KB, a JPEG block of 64 pixels needs
+// a bit or two) — a corrupt or hostile header fails with a message instead of with an out-of-memory abort.
 inline void plausible(int64_t w, int64_t h, size_t bytesPromised, size_t bytesPresent, size_t perByte) {
   need(w > 0 && h > 0 && w <= (1 << 20) && h <= (1 << 20) && w * h <= ((int64_t)1 << 30), "image size outside 1 .. 2^20 x 2^20, 2^30 pixels");
   need(bytesPromised / perByte <= bytesPresent + 1024, "corrupt image: the header promises more data than the file can hold");
@@ -745,7 +745,7 @@ inline Raster decode_jpeg(const Bytes& b) {
         if (nc == 1) {  // a single-component frame is never interleaved: its sampling factors do not matter
           comps[0].h = comps[0].v = hmax = vmax = 1;
         }
-        plausible(W, H, (size_t)W * H, b.n, 8 * 64 / 2);
+        plausible(W, H, (size_t)W * H, b.n, 1024);  // a flat image costs libjpeg 2 bits per 8 x 8 block: 256 px per byte
         const int mcusX = (W + 8 * hmax - 1) / (8 * hmax), mcusY = (H + 8 * vmax - 1) / (8 * vmax);
         for (auto& c : comps) {
           c.blocksW = mcusX * c.h;
@@ -1592,6 +1592,86 @@ inline Raster decode(const unsigned char* d, size_t n) {
     return decode_pnm(b);
   }
   throw Error(("unsupported image format: " + kind).c_str());
+}
+// geometry AND sample layout from the headers alone (what decode() would return): false when the bytes are not an
+// image this library reads. PNG needs the chunk list up to the first IDAT (a tRNS chunk adds the alpha channel), BMP
+// its palette, TIFF its directory.
+inline bool probe_info(const unsigned char* d, size_t n, int& w, int& h, int& channels, int& bitdepth) {
+  const Bytes b{d, n};
+  const std::string kind = sniff(b);
+  try {
+    if (kind == "png") {
+      PngInfo i;
+      if (!png_header(b, i)) {
+        return false;
+      }
+      bool trns = false;
+      for (size_t pos = 8; pos + 12 <= b.n;) {
+        const uint32_t len = be32(b.d + pos);
+        if (!memcmp(b.d + pos + 4, "tRNS", 4)) {
+          trns = len > 0;
+        } else if (!memcmp(b.d + pos + 4, "IDAT", 4) || !memcmp(b.d + pos + 4, "IEND", 4)) {
+          break;
+        }
+        pos += 12 + (size_t)len;
+      }
+      w = i.w, h = i.h;
+      bitdepth = i.depth == 16 ? 16 : 8;
+      channels = i.colorType == 0 ? 1 : (i.colorType == 4 || i.colorType == 6 || (trns && (i.colorType == 2 || i.colorType == 3))) ? 4 : 3;
+      return true;
+    }
+    if (kind == "jpeg") {
+      JpegInfo i;
+      if (!jpeg_header(b, i)) {
+        return false;
+      }
+      w = i.w, h = i.h, channels = i.ncomp, bitdepth = 8;
+      return true;
+    }
+    if (kind == "tiff") {
+      TiffFile f{b};
+      if (!f.open()) {
+        return false;
+      }
+      w = (int)f.get(256, 0), h = (int)f.get(257, 0);
+      const int bits = (int)f.get(258, 1);
+      bitdepth = bits;
+      channels = f.get(262, 1) == 3 ? 3 : (int)f.get(277, 1);
+      return w > 0 && h > 0;
+    }
+    if (kind == "bmp") {
+      BmpInfo i;
+      if (!bmp_header(b, i)) {
+        return false;
+      }
+      w = i.w, h = i.h, bitdepth = 8;
+      channels = i.bpp == 24 ? 3 : i.bpp == 32 ? 4 : 1;
+      if (i.bpp == 8) {
+        uint32_t used = le32(b.d + 46);
+        used = used == 0 || used > 256 ? 256 : used;
+        b.span(14 + i.headerSize, (size_t)used * 4, "truncated BMP palette");
+        const unsigned char* pal = b.d + 14 + i.headerSize;
+        for (uint32_t k = 0; k < used; ++k) {
+          if (pal[4 * k] != pal[4 * k + 1] || pal[4 * k] != pal[4 * k + 2]) {
+            channels = 3;
+          }
+        }
+      }
+      return true;
+    }
+    if (kind == "pnm") {
+      PnmInfo i;
+      if (!pnm_header(b, i)) {
+        return false;
+      }
+      w = i.w, h = i.h;
+      channels = (i.kind == 3 || i.kind == 6) ? 3 : 1;
+      bitdepth = i.maxval < 256 ? 8 : 16;
+      return true;
+    }
+  } catch (const Error&) {
+  }
+  return false;
 }
 inline bool probe_size(const unsigned char* d, size_t n, int& w, int& h) {
   const Bytes b{d, n};

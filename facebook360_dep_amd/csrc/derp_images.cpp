@@ -12,18 +12,16 @@ static thread_local std::string g_image_error;
 extern "C" const char* derp_image_last_error(void) { return g_image_error.c_str(); }
 
 extern "C" int derp_image_info(const void* bytes, size_t n, int* w, int* h, int* channels, int* bitdepth) {
-  // the colour type decides the channel count only after palettes / tRNS have been looked at: decode, keep nothing
-  try {
-    const codecs::Raster r = codecs::decode(static_cast<const unsigned char*>(bytes), n);
-    if (w) *w = r.w;
-    if (h) *h = r.h;
-    if (channels) *channels = r.channels;
-    if (bitdepth) *bitdepth = r.bitdepth;
-    return 0;
-  } catch (const std::exception& e) {
-    g_image_error = e.what();
+  int iw = 0, ih = 0, ic = 0, ib = 0;  // from the headers alone: nothing is decoded here
+  if (!codecs::probe_info(static_cast<const unsigned char*>(bytes), n, iw, ih, ic, ib)) {
+    g_image_error = std::string("unsupported image format: ") + codecs::sniff(codecs::Bytes{static_cast<const unsigned char*>(bytes), n});
     return 1;
   }
+  if (w) *w = iw;
+  if (h) *h = ih;
+  if (channels) *channels = ic;
+  if (bitdepth) *bitdepth = ib;
+  return 0;
 }
 
 extern "C" int derp_image_decode(const void* bytes, size_t n, void* out, size_t out_bytes) {

@@ -38,8 +38,12 @@ int main(int argc, char** argv) {
   }
   try {
     const codecs::Raster r = codecs::decode(data.data(), data.size());
-    int pw = -1, ph = -1;
+    int pw = -1, ph = -1, qw = -1, qh = -1, qc = -1, qb = -1;
     codecs::probe_size(data.data(), data.size(), pw, ph);
+    if (!codecs::probe_info(data.data(), data.size(), qw, qh, qc, qb) || qw != r.w || qh != r.h || qc != r.channels || qb != r.bitdepth) {
+      printf("error: probe_info says %d x %d x %d, %d bits; decode %d x %d x %d, %d bits\n", qw, qh, qc, qb, r.w, r.h, r.channels, r.bitdepth);
+      return 4;
+    }
     printf("%s %d %d %d %d %d %d\n", codecs::sniff(codecs::Bytes{data.data(), data.size()}), r.w, r.h, r.channels, r.bitdepth, pw, ph);
     if (argc > 2) {
       std::ofstream o(argv[2], std::ios::binary);
