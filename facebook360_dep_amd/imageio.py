@@ -237,8 +237,11 @@ def write_tiff(path, arr):
 
 
 def load_color_u16(path):
-    """cv_util::loadImage<Vec3w> (CvUtil.h:196-284): depth -> 16U (x257 from 8-bit), channels -> BGR."""
-    a = read_png(path)
+    """cv_util::loadImage<Vec3w> (CvUtil.h:226-284): cv::imread(IMREAD_UNCHANGED) of any format it reads, depth -> 16U
+    (x257 from 8-bit), channels -> BGR (gray replicated, alpha dropped)."""
+    a = read_image(path)
+    if a.dtype == np.float32:
+        raise ValueError("cannot use a float image as colour: %s" % path)
     if a.dtype == np.uint8:
         a = a.astype(np.uint16) * 257
     if a.ndim == 2:
@@ -247,11 +250,14 @@ def load_color_u16(path):
 
 
 def load_mask(path):
-    """cv_util::loadImage<bool> (CvUtil.h:235-239): 8-bit, threshold > 127 -> 1."""
-    a = read_png(path)
+    """cv_util::loadImage<bool> (CvUtil.h:226-262): 8-bit, threshold > 127 -> 1 per channel, then (3 / 4 channels)
+    COLOR_BGR[A]2GRAY of the 0 / 1 values, whose rounded fixed-point weights give 1 exactly when the GREEN channel's bit
+    is set (G alone rounds to 1, B + R together to 0)."""
+    a = read_image(path)
+    if a.dtype == np.float32:
+        raise ValueError("cannot use a float image as a mask: %s" % path)
     if a.ndim == 3:
-        # COLOR_BGR2GRAY is not what masks go through in practice (they are 1-channel); take channel 0
-        a = a[..., 0]
+        a = a[..., 1]
     if a.dtype == np.uint16:
         a = np.rint(a.astype(np.float64) * (255.0 / 65535.0)).astype(np.uint8)
     return (a > 127).astype(np.uint8)
