@@ -1,4 +1,4 @@
-// Test harness (CPU only) for cli_common.h's IoPool: <workers> long class-2 jobs per worker (each sleeps 40 ms), then
+// Test harness (CPU only) for cli_common.h's IoPool: <workers> long class-2 jobs per worker (each sleeps 200 ms), then
 // one class-1 and one class-0 job. Prints how long those two waited for a worker, in ms, and how many class-2 jobs ran.
 #include <atomic>
 #include <cstdio>
@@ -14,11 +14,11 @@ int main(int argc, char** argv) {
     cli::IoBatch all;
     for (int i = 0; i < workers * 4; ++i) {
       all.add(pool, [&] {
-        usleep(40000);
+        usleep(200000);
         ++ran;
       });
     }
-    usleep(10000);  // every general worker is inside a long job now
+    usleep(20000);  // every general worker is inside a long job now
     cli::Timer t;
     cli::IoBatch urgent;
     urgent.add(pool, [&] { lat1 = t.s() * 1e3; }, 1);

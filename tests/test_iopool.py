@@ -20,10 +20,10 @@ def harness(tmp_path_factory):
 def test_urgent_jobs_find_a_worker_while_the_pool_is_decoding(harness):
     lat1, lat0, ran = subprocess.check_output([harness, "12"], text=True, timeout=60).split()
     assert int(ran) == 48  # every class-2 job still ran (on the ten general workers)
-    assert float(lat1) < 15 and float(lat0) < 15, (lat1, lat0)  # not the 30 ms the first general worker needs to come free
+    assert float(lat1) < 90 and float(lat0) < 90, (lat1, lat0)  # not the 180 ms the first general worker needs to come free
 
 
 def test_small_pools_keep_every_worker_general(harness):
     lat1, lat0, ran = subprocess.check_output([harness, "4"], text=True, timeout=60).split()
     assert int(ran) == 16
-    assert 15 < float(lat1) < 200 and 15 < float(lat0) < 200, (lat1, lat0)  # behind a running job, ahead of the queued ones
+    assert 120 < float(lat1) < 390 and 120 < float(lat0) < 390, (lat1, lat0)  # behind a running job (180 ms), ahead of the queued ones
