@@ -313,7 +313,9 @@ struct Json {
 struct JsonParser {
   const std::string& s;
   size_t p = 0;
+  int depth = 0;
   explicit JsonParser(const std::string& text) : s(text) {}
+  char peek() const { return p < s.size() ? s[p] : '\0'; }  // never past the text, whatever the file holds
   void ws() {
     while (p < s.size() && (s[p] == ' ' || s[p] == '\t' || s[p] == '\n' || s[p] == '\r')) {
       ++p;
@@ -325,13 +327,20 @@ struct JsonParser {
     if (p >= s.size()) {
       bad("unexpected end");
     }
+    if (++depth > 64) {
+      bad("nesting deeper than 64 levels");
+    }
+    struct Leave {
+      int& d;
+      ~Leave() { --d; }
+    } leave{depth};
     Json j;
     const char c = s[p];
     if (c == '{') {
       j.kind = Json::Obj;
       ++p;
       ws();
-      if (s[p] == '}') {
+      if (peek() == '}') {
         ++p;
         return j;
       }
@@ -342,17 +351,17 @@ struct JsonParser {
           bad("object key must be a string");
         }
         ws();
-        if (s[p] != ':') {
+        if (peek() != ':') {
           bad("expected ':'");
         }
         ++p;
         j.obj.emplace_back(k.str, value());
         ws();
-        if (s[p] == ',') {
+        if (peek() == ',') {
           ++p;
           continue;
         }
-        if (s[p] == '}') {
+        if (peek() == '}') {
           ++p;
           break;
         }
@@ -362,18 +371,18 @@ struct JsonParser {
       j.kind = Json::Arr;
       ++p;
       ws();
-      if (s[p] == ']') {
+      if (peek() == ']') {
         ++p;
         return j;
       }
       for (;;) {
         j.arr.push_back(value());
         ws();
-        if (s[p] == ',') {
+        if (peek() == ',') {
           ++p;
           continue;
         }
-        if (s[p] == ']') {
+        if (peek() == ']') {
           ++p;
           break;
         }
@@ -388,13 +397,22 @@ struct JsonParser {
           switch (s[p]) {
             case 'n': j.str += '\n'; break;
             case 't': j.str += '\t'; break;
-            case 'u': p += 4; j.str += '?'; break;
+            case 'u':
+              if (p + 4 >= s.size()) {
+                bad("truncated \\u escape");
+              }
+              p += 4;
+              j.str += '?';
+              break;
             default: j.str += s[p];
           }
         } else {
           j.str += s[p];
         }
         ++p;
+      }
+      if (p >= s.size()) {
+        bad("unterminated string");
       }
       ++p;
     } else if (s.compare(p, 4, "true") == 0) {
@@ -792,8 +810,9 @@ inline bool exr_header(const std::string& data, const fs::path& path, ExrInfo& i
     } else if (name == "dataWindow" && size == 16) {
       int32_t b[4];
       memcpy(b, data.data() + val, 16);
-      info.w = b[2] - b[0] + 1;
-      info.h = b[3] - b[1] + 1;
+      const int64_t ww = (int64_t)b[2] - b[0] + 1, hh = (int64_t)b[3] - b[1] + 1;
+      info.w = ww > 0 && ww <= (1 << 20) ? (int)ww : 0;
+      info.h = hh > 0 && hh <= (1 << 20) ? (int)hh : 0;
       haveWindow = b[0] == 0 && b[1] == 0;
     }
     pos = val + size;
@@ -836,6 +855,9 @@ inline std::vector<float> read_exr_f32(const fs::path& path, int& w, int& h) {
   exr_header(data, path, info, true);
   w = info.w;
   h = info.h;
+  // sizes come from the file: a data window the file's bytes cannot fill (ZIP shrinks float data by a few per cent, and
+  // deflate by 1032 : 1 at the very most) is refused before anything is allocated
+  CHECK_MSG(w <= (1 << 20) && h <= (1 << 20) && (size_t)w * h * 4 / 1032 <= data.size(), "corrupt OpenEXR header (data window): " + path.string());
   const int lines = info.compression == 3 ? 16 : 1;
   const int blocks = (h + lines - 1) / lines;
   CHECK_MSG(info.tableOffset + (size_t)blocks * 8 <= data.size(), "truncated OpenEXR file: " + path.string());
