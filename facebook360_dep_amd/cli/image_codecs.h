@@ -1042,6 +1042,308 @@ inline Raster decode_jpeg(const Bytes& b) {
   return img;
 }
 
+// ---- JPEG encoder: what cv::imwrite(".jpg", 8-bit image) leaves behind with its defaults (quality 95, baseline,
+// 4:2:0, the standard's Huffman tables, no restart markers) — libjpeg's compressor restated: jccolor.c's 16-bit RGB ->
+// YCbCr tables, jcsample.c's h2v2 box filter with its alternating 1 / 2 rounding bias over edge-replicated rows,
+// jfdctint.c's "islow" forward DCT, jcdctmgr.c's round-half-up quantisation, jccoefct.c's dummy blocks (zero AC, the
+// neighbour's DC) beyond the image, jchuff.c's entropy coder; the tables are ITU T.81 Annex K's. The pyramid builder
+// uses it so that a JPEG source directory yields JPEG level directories like scripts/render/resize.py:82-85 does;
+// byte-identical to libjpeg-turbo's output (tests/test_image_codecs.py compares with Pillow's encoder).
+static const uint8_t kJpegStdLumaQ[64] = {16, 11, 10, 16, 24,  40,  51,  61,  12, 12, 14, 19, 26,  58,  60,  55,  14, 13, 16, 24, 40,  57,
+                                          69, 56, 14, 17, 22,  29,  51,  87,  80, 62, 18, 22, 37,  56,  68,  109, 103, 77, 24, 35, 55,  64,
+                                          81, 104, 113, 92, 49, 64,  78,  87,  103, 121, 120, 101, 72, 92, 95,  98,  112, 100, 103, 99};
+static const uint8_t kJpegStdChromaQ[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99,
+                                            99, 99, 47, 66, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99,
+                                            99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+static const uint8_t kJpegStdBits[4][16] = {{0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0},      // DC luminance
+                                            {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125},    // AC luminance
+                                            {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0},      // DC chrominance
+                                            {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119}};   // AC chrominance
+static const uint8_t kJpegStdDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+static const uint8_t kJpegStdAcLuma[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1,
+    0x08, 0x23, 0x42, 0xb1, 0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26,
+    0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56,
+    0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85,
+    0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa,
+    0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4, 0xd5, 0xd6,
+    0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+static const uint8_t kJpegStdAcChroma[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42,
+    0x91, 0xa1, 0xb1, 0xc1, 0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19,
+    0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36, 0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55,
+    0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83,
+    0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8,
+    0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3, 0xd4,
+    0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9,
+    0xfa};
+
+inline void jpeg_fdct_islow(int* d) {  // jfdctint.c, in place on 64 level-shifted samples
+  const int64_t F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299, F1847 = 15137,
+                F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  auto descale = [](int64_t x, int nb) { return (int)((x + ((int64_t)1 << (nb - 1))) >> nb); };
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < 8; ++i) {
+      int* p = pass == 0 ? d + 8 * i : d + i;
+      const int st = pass == 0 ? 1 : 8;
+      const int64_t t0 = p[0] + p[7 * st], t7 = p[0] - p[7 * st], t1 = p[st] + p[6 * st], t6 = p[st] - p[6 * st], t2 = p[2 * st] + p[5 * st],
+                    t5 = p[2 * st] - p[5 * st], t3 = p[3 * st] + p[4 * st], t4 = p[3 * st] - p[4 * st];
+      const int64_t t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+      const int lo = pass == 0 ? 13 - 2 : 13 + 2;
+      p[0] = pass == 0 ? (int)((t10 + t11) * 4) : descale(t10 + t11, 2);
+      p[4 * st] = pass == 0 ? (int)((t10 - t11) * 4) : descale(t10 - t11, 2);
+      int64_t z1 = (t12 + t13) * F0541;
+      p[2 * st] = descale(z1 + t13 * F0765, lo);
+      p[6 * st] = descale(z1 + t12 * (-F1847), lo);
+      z1 = t4 + t7;
+      int64_t z2 = t5 + t6, z3 = t4 + t6, z4 = t5 + t7;
+      const int64_t z5 = (z3 + z4) * F1175;
+      const int64_t m4 = t4 * F0298, m5 = t5 * F2053, m6 = t6 * F3072, m7 = t7 * F1501;
+      z1 *= -F0899, z2 *= -F2562, z3 *= -F1961, z4 *= -F0390;
+      z3 += z5;
+      z4 += z5;
+      p[7 * st] = descale(m4 + z1 + z3, lo);
+      p[5 * st] = descale(m5 + z2 + z4, lo);
+      p[3 * st] = descale(m6 + z2 + z3, lo);
+      p[st] = descale(m7 + z1 + z4, lo);
+    }
+  }
+}
+
+// px: 8-bit samples, interleaved R, G, B (channels 3) or gray (channels 1), row-major
+inline std::vector<unsigned char> encode_jpeg(const uint8_t* px, int W, int H, int channels, int quality = 95) {
+  need((channels == 1 || channels == 3) && W > 0 && H > 0 && W < 65536 && H < 65536, "JPEG encoder: 1 or 3 channels, sides below 65536");
+  quality = std::min(std::max(quality, 1), 100);
+  const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;  // jpeg_quality_scaling
+  int qt[2][64];
+  for (int t = 0; t < 2; ++t) {
+    for (int i = 0; i < 64; ++i) {
+      const long v = ((long)(t ? kJpegStdChromaQ : kJpegStdLumaQ)[i] * scale + 50) / 100;
+      qt[t][i] = (int)std::min(std::max(v, 1L), 255L);  // force_baseline
+    }
+  }
+  struct Table {
+    uint16_t code[256];
+    uint8_t size[256];
+  } huff[4];
+  const uint8_t* vals[4] = {kJpegStdDcVals, kJpegStdAcLuma, kJpegStdDcVals, kJpegStdAcChroma};
+  for (int t = 0; t < 4; ++t) {
+    memset(huff[t].size, 0, sizeof huff[t].size);
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+      for (int i = 0; i < kJpegStdBits[t][len - 1]; ++i, ++k, ++code) {
+        huff[t].code[vals[t][k]] = (uint16_t)code;
+        huff[t].size[vals[t][k]] = (uint8_t)len;
+      }
+      code <<= 1;
+    }
+  }
+  std::vector<unsigned char> out;
+  auto put16 = [&](int v) {
+    out.push_back((unsigned char)(v >> 8));
+    out.push_back((unsigned char)v);
+  };
+  out.push_back(0xff), out.push_back(0xd8);
+  static const unsigned char jfif[] = {0xff, 0xe0, 0, 16, 'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0};
+  out.insert(out.end(), jfif, jfif + sizeof jfif);
+  for (int t = 0; t < (channels == 3 ? 2 : 1); ++t) {
+    out.push_back(0xff), out.push_back(0xdb);
+    put16(67);
+    out.push_back((unsigned char)t);
+    for (int k = 0; k < 64; ++k) {
+      out.push_back((unsigned char)qt[t][kJpegZigzag[k]]);
+    }
+  }
+  out.push_back(0xff), out.push_back(0xc0);
+  put16(8 + 3 * channels);
+  out.push_back(8);
+  put16(H);
+  put16(W);
+  out.push_back((unsigned char)channels);
+  for (int c = 0; c < channels; ++c) {
+    out.push_back((unsigned char)(c + 1));
+    out.push_back((unsigned char)(c == 0 && channels == 3 ? 0x22 : 0x11));
+    out.push_back((unsigned char)(c ? 1 : 0));
+  }
+  for (int t = 0; t < (channels == 3 ? 4 : 2); ++t) {
+    int n = 0;
+    for (int i = 0; i < 16; ++i) {
+      n += kJpegStdBits[t][i];
+    }
+    out.push_back(0xff), out.push_back(0xc4);
+    put16(19 + n);
+    out.push_back((unsigned char)(((t & 1) << 4) | (t >> 1)));
+    out.insert(out.end(), kJpegStdBits[t], kJpegStdBits[t] + 16);
+    out.insert(out.end(), vals[t], vals[t] + n);
+  }
+  out.push_back(0xff), out.push_back(0xda);
+  put16(6 + 2 * channels);
+  out.push_back((unsigned char)channels);
+  for (int c = 0; c < channels; ++c) {
+    out.push_back((unsigned char)(c + 1));
+    out.push_back((unsigned char)(c ? 0x11 : 0x00));
+  }
+  out.push_back(0), out.push_back(63), out.push_back(0);
+
+  // ---- component planes: colour conversion, then (chroma) the 2 x 2 box over edge-replicated rows and columns
+  const int hs = channels == 3 ? 2 : 1;  // luma sampling factor = MCU size / 8
+  const int mcusX = (W + 8 * hs - 1) / (8 * hs), mcusY = (H + 8 * hs - 1) / (8 * hs);
+  struct Comp {
+    int w, h;        // downsampled_width / _height
+    int bw, bh;      // width_in_blocks / height_in_blocks (real blocks)
+    int pw, ph;      // plane size: padded to whole MCUs
+    std::vector<uint8_t> s;
+  } comp[3];
+  for (int c = 0; c < channels; ++c) {
+    const int f = c == 0 ? hs : 1;
+    comp[c].w = (W * f + hs - 1) / hs;
+    comp[c].h = (H * f + hs - 1) / hs;
+    comp[c].bw = (comp[c].w + 7) / 8;
+    comp[c].bh = (comp[c].h + 7) / 8;
+    comp[c].pw = mcusX * f * 8;
+    comp[c].ph = mcusY * f * 8;
+    comp[c].s.assign((size_t)comp[c].pw * comp[c].ph, 0);
+  }
+  // full-resolution Y / Cb / Cr rows with the right edge replicated to the chroma blocks' extent (expand_right_edge)
+  // and, for an odd height, the last row repeated to complete its row group (expand_bottom_edge)
+  const int fullW = channels == 3 ? std::max(comp[0].bw * 8, comp[1].bw * 16) : comp[0].bw * 8;
+  const int fullH = channels == 3 ? ((H + 1) & ~1) : H;
+  std::vector<uint8_t> ycc[3];
+  for (int c = 0; c < channels; ++c) {
+    ycc[c].resize((size_t)fullW * fullH);
+  }
+  for (int y = 0; y < fullH; ++y) {
+    const uint8_t* row = px + (size_t)std::min(y, H - 1) * W * channels;
+    for (int x = 0; x < fullW; ++x) {
+      const uint8_t* s = row + (size_t)std::min(x, W - 1) * channels;
+      if (channels == 1) {
+        ycc[0][(size_t)y * fullW + x] = s[0];
+        continue;
+      }
+      const int64_t r = s[0], g = s[1], b = s[2];
+      ycc[0][(size_t)y * fullW + x] = (uint8_t)((19595 * r + 38470 * g + 7471 * b + 32768) >> 16);
+      ycc[1][(size_t)y * fullW + x] = (uint8_t)((-11059 * r - 21709 * g + 32768 * b + (128 << 16) + 32767) >> 16);
+      ycc[2][(size_t)y * fullW + x] = (uint8_t)((32768 * r - 27439 * g - 5329 * b + (128 << 16) + 32767) >> 16);
+    }
+  }
+  for (int c = 0; c < channels; ++c) {
+    Comp& k = comp[c];
+    const bool sub = channels == 3 && c > 0;
+    const int rows = sub ? fullH / 2 : fullH, cols = k.bw * 8;
+    for (int y = 0; y < k.ph; ++y) {
+      uint8_t* o = &k.s[(size_t)y * k.pw];
+      const int sy = std::min(y, rows - 1);  // below the image: the last (downsampled) row again
+      if (!sub) {
+        memcpy(o, &ycc[c][(size_t)sy * fullW], (size_t)cols);
+      } else {
+        const uint8_t* a = &ycc[c][(size_t)(2 * sy) * fullW];
+        const uint8_t* bb = a + fullW;
+        int bias = 1;
+        for (int x = 0; x < cols; ++x) {
+          o[x] = (uint8_t)((a[2 * x] + a[2 * x + 1] + bb[2 * x] + bb[2 * x + 1] + bias) >> 2);
+          bias ^= 3;
+        }
+      }
+    }
+  }
+
+  // ---- entropy coding, MCU by MCU
+  uint64_t acc = 0;
+  int nacc = 0;
+  auto emit = [&](unsigned code, int size) {
+    acc = (acc << size) | (code & ((1u << size) - 1));
+    nacc += size;
+    while (nacc >= 8) {
+      const unsigned char byte = (unsigned char)(acc >> (nacc - 8));
+      out.push_back(byte);
+      if (byte == 0xff) {
+        out.push_back(0);
+      }
+      nacc -= 8;
+    }
+  };
+  int lastDc[3] = {0, 0, 0};
+  int prevDcOfBlock = 0;  // DC of the block coded before (jccoefct.c's dummy blocks copy it)
+  for (int my = 0; my < mcusY; ++my) {
+    for (int mx = 0; mx < mcusX; ++mx) {
+      for (int c = 0; c < channels; ++c) {
+        const Comp& k = comp[c];
+        const int f = c == 0 ? hs : 1;
+        for (int by = 0; by < f; ++by) {
+          for (int bx = 0; bx < f; ++bx) {
+            const int blockX = mx * f + bx, blockY = my * f + by;
+            int blk[64];
+            const bool real = blockX < k.bw && blockY < k.bh;
+            if (real) {
+              for (int y = 0; y < 8; ++y) {
+                const uint8_t* srow = &k.s[(size_t)(blockY * 8 + y) * k.pw + blockX * 8];
+                for (int x = 0; x < 8; ++x) {
+                  blk[8 * y + x] = srow[x] - 128;
+                }
+              }
+              jpeg_fdct_islow(blk);
+              const int* q = qt[c ? 1 : 0];
+              for (int i = 0; i < 64; ++i) {
+                const int div = q[i] * 8;
+                const int v = blk[i];
+                blk[i] = v < 0 ? -((-v + (div >> 1)) / div) : (v + (div >> 1)) / div;
+              }
+            } else {  // beyond the component's real blocks: zero AC, the DC of the block coded just before
+              memset(blk, 0, sizeof blk);
+              blk[0] = prevDcOfBlock;
+            }
+            prevDcOfBlock = blk[0];
+            const Table& dc = huff[c ? 2 : 0];
+            const Table& ac = huff[c ? 3 : 1];
+            int diff = blk[0] - lastDc[c];
+            lastDc[c] = blk[0];
+            int t = diff < 0 ? -diff : diff, t2 = diff < 0 ? diff - 1 : diff, nbits = 0;
+            while (t) {
+              ++nbits;
+              t >>= 1;
+            }
+            emit(dc.code[nbits], dc.size[nbits]);
+            if (nbits) {
+              emit((unsigned)t2, nbits);
+            }
+            int run = 0;
+            for (int kz = 1; kz < 64; ++kz) {
+              const int v = blk[kJpegZigzag[kz]];
+              if (v == 0) {
+                ++run;
+                continue;
+              }
+              while (run > 15) {
+                emit(ac.code[0xf0], ac.size[0xf0]);
+                run -= 16;
+              }
+              t = v < 0 ? -v : v;
+              t2 = v < 0 ? v - 1 : v;
+              nbits = 0;
+              while (t) {
+                ++nbits;
+                t >>= 1;
+              }
+              emit(ac.code[(run << 4) + nbits], ac.size[(run << 4) + nbits]);
+              emit((unsigned)t2, nbits);
+              run = 0;
+            }
+            if (run > 0) {
+              emit(ac.code[0], ac.size[0]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (nacc) {
+    emit(0x7f, 8 - nacc);  // pad the last byte with ones
+  }
+  out.push_back(0xff), out.push_back(0xd9);
+  return out;
+}
+
 // ================================================================================================ TIFF
 // TIFF 6.0 (+ the Deflate / SampleFormat supplements), classic (not BigTIFF), first directory. What OpenCV's TiffDecoder
 // returns under IMREAD_UNCHANGED: 8-bit images go through libtiff's RGBA interface (palette expanded, min-is-white

@@ -53,3 +53,29 @@ extern "C" int derp_image_decode(const void* bytes, size_t n, void* out, size_t 
     return 1;
   }
 }
+
+extern "C" int derp_jpeg_encode(const void* pixels, int w, int h, int channels, int quality, void* out, size_t cap, size_t* size) {
+  try {
+    codecs::need(pixels && size && (channels == 1 || channels == 3) && w > 0 && h > 0, "derp_jpeg_encode: 8-bit gray or B, G, R pixels");
+    const uint8_t* src = static_cast<const uint8_t*>(pixels);
+    std::vector<uint8_t> rgb;
+    if (channels == 3) {  // OpenCV's order in, the file's order inside
+      rgb.resize((size_t)w * h * 3);
+      for (size_t i = 0; i < (size_t)w * h; ++i) {
+        rgb[3 * i] = src[3 * i + 2], rgb[3 * i + 1] = src[3 * i + 1], rgb[3 * i + 2] = src[3 * i];
+      }
+      src = rgb.data();
+    }
+    const std::vector<unsigned char> j = codecs::encode_jpeg(src, w, h, channels, quality);
+    *size = j.size();
+    if (out && cap >= j.size()) {
+      memcpy(out, j.data(), j.size());
+      return 0;
+    }
+    g_image_error = "derp_jpeg_encode: output buffer too small (the size needed is returned)";
+    return out ? 1 : 0;  // a call without a buffer asks for the size
+  } catch (const std::exception& e) {
+    g_image_error = e.what();
+    return 1;
+  }
+}

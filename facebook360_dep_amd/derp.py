@@ -51,7 +51,7 @@ EXPORTS = [
     "derp_options_default", "derp_create", "derp_destroy", "derp_last_error", "derp_set_options", "derp_set_pyramid",
     "derp_build_pyramid_color", "derp_build_pyramid_foreground_mask", "derp_build_pyramid_background_disparity",
     "derp_download_level_color", "derp_download_level_mask", "derp_download_level_background", "derp_resize_area",
-    "derp_generate_foreground_mask", "derp_image_info", "derp_image_decode", "derp_image_last_error",
+    "derp_generate_foreground_mask", "derp_image_info", "derp_image_decode", "derp_image_last_error", "derp_jpeg_encode",
     "derp_upload_color", "derp_upload_foreground_mask", "derp_upload_background_disparity", "derp_upload_disparity",
     "derp_process_level", "derp_process_pyramid", "derp_synchronize", "derp_download_disparity", "derp_download_cost",
     "derp_level_begin", "derp_stage_reproject_colors", "derp_stage_brute_force", "derp_stage_random_proposals",

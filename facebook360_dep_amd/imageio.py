@@ -203,6 +203,29 @@ def read_image(path):
     return np.ascontiguousarray(out[..., 0] if ch.value == 1 else out)
 
 
+def write_jpeg(path, arr, quality=95):
+    """cv2.imwrite(path_with_a_jpeg_extension, arr) with OpenCV's defaults: uint8 [h, w] or [h, w, 3] (B, G, R) through
+    the C-ABI's derp_jpeg_encode — byte for byte what libjpeg-turbo writes at that quality (baseline, 4:2:0)."""
+    import ctypes as C
+
+    from . import derp
+
+    a = np.ascontiguousarray(arr)
+    if a.dtype != np.uint8 or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] != 3):
+        raise ValueError("JPEG holds 8-bit gray or 3-channel images")
+    lib = derp.lib()
+    lib.derp_image_last_error.restype = C.c_char_p
+    h, w = a.shape[:2]
+    ch = 1 if a.ndim == 2 else 3
+    size = C.c_size_t(0)
+    cap = w * h * ch * 2 + 4096  # libjpeg's own worst case is well below two bytes per sample
+    buf = (C.c_ubyte * cap)()
+    if lib.derp_jpeg_encode(a.ctypes.data_as(C.c_void_p), w, h, ch, int(quality), buf, C.c_size_t(cap), C.byref(size)):
+        raise ValueError("failed to save image: %s (%s)" % (path, lib.derp_image_last_error().decode()))
+    with open(path, "wb") as f:
+        f.write(memoryview(buf)[: size.value])
+
+
 def write_tiff(path, arr):
     """A baseline little-endian TIFF, one Deflate-compressed strip: uint8 / uint16 [h, w] or [h, w, 3|4] in B, G, R [, A]
     order (stored R, G, B [, A]; a fourth sample is declared as un-associated alpha), float32 [h, w]. Lossless, so

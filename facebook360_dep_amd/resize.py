@@ -49,10 +49,10 @@ def resize_camera(g, src_dir, dst_dir, camera, rig_resolution, frame, threshold)
     img = imageio.read_pfm(original_file) if ext == ".pfm" else imageio.read_image(original_file)
     if img.ndim == 3 and img.shape[2] == 4:
         img = img[..., :3]
-    # cv2.imwrite(new_file, scaled) keeps the source's container. PNG and TIFF stay what they are; a lossy or exotic
-    # source (JPEG, BMP, PNM) is written as PNG under a .png name — the level files then hold exactly the resized
-    # samples instead of a second generation of JPEG loss (the one deliberate difference from resize.py:82-85).
-    out_ext = ext if ext.lower() in (".pfm", ".png", ".tif", ".tiff") else ".png"
+    # cv2.imwrite(new_file, scaled) keeps the source's container (resize.py:82-85): PNG, TIFF and 8-bit JPEG (quality 95,
+    # byte for byte libjpeg's output) stay what they are; BMP and PNM sources are written as PNG under a .png name.
+    jpeg = ext.lower() in (".jpg", ".jpeg", ".jpe") and img.dtype == np.uint8
+    out_ext = ext if jpeg or ext.lower() in (".pfm", ".png", ".tif", ".tiff") else ".png"
     frame_fn = os.path.splitext(frame_fn)[0] + out_ext
     for level, (width, height) in enumerate(level_sizes(rig_resolution[0], rig_resolution[1])):
         new_file = os.path.join(dst_dir, f"level_{level}", camera, frame_fn)
@@ -71,6 +71,8 @@ def resize_camera(g, src_dir, dst_dir, camera, rig_resolution, frame, threshold)
             imageio.write_pfm(new_file, scaled)
         elif out_ext.lower() in (".tif", ".tiff"):
             imageio.write_tiff(new_file, scaled)
+        elif jpeg:
+            imageio.write_jpeg(new_file, scaled)
         elif scaled.dtype == np.uint16:
             imageio.write_png16(new_file, scaled)
         else:

@@ -137,6 +137,11 @@ int derp_download_level_background(derp_ctx* ctx, int level, int dst, float* dis
 int derp_image_info(const void* bytes, size_t n, int* w, int* h, int* channels, int* bitdepth);
 int derp_image_decode(const void* bytes, size_t n, void* out, size_t out_bytes);
 const char* derp_image_last_error(void);
+/* What cv::imwrite(".jpg", 8-bit image) writes with its defaults (scripts/render/resize.py:82-85 on a JPEG source
+ * directory): baseline JPEG, 4:2:0, the standard tables, `quality` as libjpeg scales it (OpenCV's default: 95) — libjpeg's
+ * compressor restated, byte-identical to libjpeg-turbo's output. pixels: w * h * channels bytes, gray or B, G, R.
+ * out == NULL: only *size is set (the bytes needed); otherwise 0 and *size bytes written, non-zero if cap is too small. */
+int derp_jpeg_encode(const void* pixels, int w, int h, int channels, int quality, void* out, size_t cap, size_t* size);
 
 /* one image: kind 0 = BGR u16 x3, 1 = u8 x1, 2 = f32 x1, 3 = BGR f32 x3 (cv_util::resizeImage<Vec3f>,
  * CvUtil.h:139-147 — the colour guide of UpsampleDisparity.cpp:117). Shrinking only. */

@@ -44,5 +44,16 @@ keep("rgb_64x48_adobe_rgb_q90", Image.fromarray(scene(64, 48, 3)), quality=90, k
 noise = Image.fromarray(np.random.default_rng(1).integers(0, 256, (45, 52, 3)).astype(np.uint8))
 keep("noise_52x45_420_q10_progressive", noise, quality=10, subsampling=2, progressive=True)
 keep("noise_52x45_444_q100", noise, quality=100, subsampling=0)
+# the ENCODER's vectors: CRC-32 of the file libjpeg-turbo writes for a synthetic picture (scene(w, h, c) of the test module)
+# at a quality; the test encodes the same picture with derp_jpeg_encode and must produce the same bytes
+encoder = {}
+for (w, h, c, q) in ((37, 29, 3, 95), (64, 48, 1, 95), (7, 5, 3, 75), (100, 75, 3, 95), (17, 9, 3, 30), (16, 16, 1, 100)):
+    a = scene(w, h, c)
+    path = os.path.join(HERE, "_tmp.jpg")
+    Image.fromarray(a if c == 3 else a[..., 0]).save(path, quality=q)
+    data = open(path, "rb").read()
+    os.remove(path)
+    encoder["%dx%dx%d_q%d" % (w, h, c, q)] = {"bytes": len(data), "crc32": zlib.crc32(data)}
+json.dump(encoder, open(os.path.join(HERE, "encoder_expected.json"), "w"), indent=1, sort_keys=True)
 json.dump(expected, open(os.path.join(HERE, "expected.json"), "w"), indent=1, sort_keys=True)
 print(len(expected), "vectors; libjpeg", features.version("jpg"), "turbo:", features.check_feature("libjpeg_turbo"))

@@ -563,7 +563,7 @@ def test_resize_module_builds_level_directories(dataset, tmp_path):
             got = dio.read_png(str(dst / ("level_%d" % level) / cam / "000000.png"))
             assert np.array_equal(got, O.cv_resize_area(imgs[cam], widths[level], widths[level])), (level, cam)
     # sources in other containers (resize.py reads them with cv2.imread): 16-bit TIFF stays TIFF, level for level the
-    # same samples as from the PNG; 8-bit JPEG comes out as PNG holding the resized libjpeg decode
+    # same samples as from the PNG; 8-bit JPEG comes out as JPEG: libjpeg's encoding of the resized libjpeg decode
     from tests.test_image_codecs import tiff_bytes
 
     cam = rig["cameras"][0]["id"]
@@ -589,10 +589,11 @@ def test_resize_module_builds_level_directories(dataset, tmp_path):
     p = subprocess.run([sys.executable, "-m", "facebook360_dep_amd.resize", "--src_dir", str(src3), "--dst_dir", str(dst3),
                         "--rig", str(rigf)], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
-    for level in (2, 4, 9):
-        got = dio.read_png(str(dst3 / ("level_%d" % level) / cam / "000000.png"))
+    for level in (2, 4, 9):  # JPEG in, JPEG out (cv2.imwrite's defaults: quality 95, 4:2:0), byte for byte libjpeg's file
         want = O.cv_resize_area(smooth[cam].astype(np.uint16), widths[level], widths[level]).astype(np.uint8)
-        assert got.dtype == np.uint8 and np.array_equal(got, want), level
+        Image.fromarray(np.ascontiguousarray(want[..., ::-1])).save(str(tmp_path / "want.jpg"), quality=95)
+        got = open(str(dst3 / ("level_%d" % level) / cam / "000000.jpg"), "rb").read()
+        assert got == open(str(tmp_path / "want.jpg"), "rb").read(), level
 
 
 def test_generate_foreground_masks_cli(dataset, tmp_path):

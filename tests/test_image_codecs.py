@@ -638,3 +638,35 @@ def test_python_host_reads_the_same_through_the_c_abi(tmp_path):
     open(path, "wb").write(b"RIFF\x10\0\0\0WEBPVP8 ")
     with pytest.raises(ValueError, match="webp"):
         dio.read_image(path)
+
+
+def test_jpeg_encoder_writes_libjpegs_bytes(tmp_path):
+    """derp_jpeg_encode (what the pyramid builder's cv2.imwrite stand-in calls for JPEG level directories): the committed
+    CRCs are those of the files libjpeg-turbo wrote for the same pictures (gen_codec_vectors.py); with Pillow at hand,
+    a sweep of sizes (whole, partial and single MCUs; odd sides), gray and colour, smooth and noisy, four qualities —
+    byte for byte."""
+    from facebook360_dep_amd import imageio as dio
+
+    path = str(tmp_path / "t.jpg")
+    expected = json.load(open(os.path.join(GOLDEN, "encoder_expected.json")))
+    for key, e in sorted(expected.items()):
+        dims, q = key.split("_q")
+        w, h, c = (int(v) for v in dims.split("x"))
+        a = scene(w, h, c)
+        dio.write_jpeg(path, a[..., ::-1] if c == 3 else a[..., 0], int(q))
+        data = open(path, "rb").read()
+        assert len(data) == e["bytes"] and zlib.crc32(data) == e["crc32"], key
+        back = dio.read_image(path)  # and the decoder reads its sibling's files
+        assert back.shape == ((h, w, 3) if c == 3 else (h, w))
+    if Image is None:
+        return
+    rng = np.random.default_rng(5)
+    for (w, h) in [(16, 16), (37, 53), (8, 8), (1, 1), (2, 3), (17, 9), (33, 31), (15, 16), (16, 15), (130, 70)]:
+        for c in (3, 1):
+            for a in (scene(w, h, c), rng.integers(0, 256, (h, w, c)).astype(np.uint8)):
+                for q in (95, 75, 30, 100):
+                    dio.write_jpeg(path, a[..., ::-1] if c == 3 else a[..., 0], q)
+                    Image.fromarray(a if c == 3 else a[..., 0]).save(path + ".pil.jpg", quality=q)
+                    assert open(path, "rb").read() == open(path + ".pil.jpg", "rb").read(), (w, h, c, q)
+    with pytest.raises(ValueError):
+        dio.write_jpeg(path, np.zeros((4, 4, 3), np.uint16))
