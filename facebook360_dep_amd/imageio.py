@@ -218,7 +218,7 @@ def write_jpeg(path, arr, quality=95):
     h, w = a.shape[:2]
     ch = 1 if a.ndim == 2 else 3
     size = C.c_size_t(0)
-    cap = w * h * ch * 2 + 4096  # libjpeg's own worst case is well below two bytes per sample
+    cap = w * h * ch * 4 + 4096  # a coefficient costs at most a 16-bit code + 11 bits: under four bytes per sample
     buf = (C.c_ubyte * cap)()
     if lib.derp_jpeg_encode(a.ctypes.data_as(C.c_void_p), w, h, ch, int(quality), buf, C.c_size_t(cap), C.byref(size)):
         raise ValueError("failed to save image: %s (%s)" % (path, lib.derp_image_last_error().decode()))
