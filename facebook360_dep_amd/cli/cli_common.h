@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cmath>
 #include <condition_variable>
 #include <deque>
@@ -126,7 +127,8 @@ struct Flags {
   void boolean(const std::string& n, bool d, const std::string& h) { def("bool", n, d ? "true" : "false", h); }
 
   std::string s(const std::string& n) const { return defs.at(n).value; }
-  int i(const std::string& n) const { return atoi(defs.at(n).value.c_str()); }
+  static int int_base(const std::string& v) { return v.size() > 1 && v[0] == '0' && (v[1] == 'x' || v[1] == 'X') ? 16 : 10; }
+  int i(const std::string& n) const { return (int)strtoll(defs.at(n).value.c_str(), nullptr, int_base(defs.at(n).value)); }
   double d(const std::string& n) const { return atof(defs.at(n).value.c_str()); }
   bool b(const std::string& n) const {
     const std::string& v = defs.at(n).value;
@@ -145,8 +147,16 @@ struct Flags {
     }
     if (it->second.type == "int32" || it->second.type == "double") {
       char* end = nullptr;
-      strtod(value.c_str(), &end);
-      if (value.empty() || (end && *end)) {
+      if (it->second.type == "int32") {  // gflags: strtoll, base 16 after "0x" and 10 otherwise, the whole token, 32-bit range
+        errno = 0;
+        const long long v = strtoll(value.c_str(), &end, int_base(value));
+        if (errno == ERANGE || v < INT32_MIN || v > INT32_MAX) {
+          end = nullptr;
+        }
+      } else {
+        strtod(value.c_str(), &end);
+      }
+      if (value.empty() || !end || *end) {
         fprintf(stderr, "ERROR: illegal value '%s' specified for %s flag '%s'\n", value.c_str(),
                 it->second.type.c_str(), name.c_str());
         exit(1);
