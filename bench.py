@@ -168,9 +168,56 @@ def cpu_baseline(rig, sizes, frame, res, n_cams, mode="auto"):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` started plainly (no launcher: RANK / WORLD_SIZE unset) with N > 1: start the N ranks
+    here, one process per GPU — the environment `python -m torch.distributed.run --nproc-per-node N` would give them —
+    and let rank 0 print the one JSON line. Refuses (non-zero exit, nothing on stdout) when the node has fewer than N
+    devices: a line that says n_gpus 1 for a --gpus 8 request would be taken for a scaling measurement."""
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    single = bool(os.environ.get("DERP_BENCH_SINGLE_DEVICE"))  # developer check of the N > 1 path on a 1-GPU box
+    if have < args.gpus and not single:
+        raise SystemExit("bench.py: --gpus %d asked for, %d visible device(s): refusing to measure fewer GPUs than "
+                         "requested" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = []
+    try:
+        # a rank that dies leaves the others in a collective: take the whole job down with it
+        while len(rcs) < len(procs):
+            rcs = [p.poll() for p in procs]
+            if any(rc not in (None, 0) for rc in rcs):
+                break
+            rcs = [rc for rc in rcs if rc is not None]
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None and any(q.poll() not in (None, 0) for q in procs):
+                p.kill()
+        rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit("bench.py: rank(s) failed: %s" % ", ".join("rank %d rc %d" % b for b in bad))
+
+
 def main():
     args = parse()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL peer-memory handles need it here
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return launch_ranks(args)
     import numpy as np  # noqa: F401
     import torch
 
@@ -179,8 +226,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if args.gpus != world:  # never print a line whose n_gpus is not what --gpus asked for
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     dist = None
     if os.environ.get("DERP_BENCH_SINGLE_DEVICE"):  # developer check of the N>1 path on a 1-GPU box
         local_rank = 0

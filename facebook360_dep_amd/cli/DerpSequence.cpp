@@ -363,7 +363,10 @@ int main(int argc, char** argv) {
     // frame later, from the filter's scratch over the copy stream — behind the compute of the frames that follow,
     // instead of all at once after the level's last frame (at the finest level that was 4.3 GB of PFMs and most of a
     // second at the very end of the job). What the two directories receive is the same filtered level either way.
-    int nFiltered = 0, nSaved = 0;
+    // Per frame, not a running prefix: on a rank whose first owned frame reaches into another rank's chunk (every rank
+    // but the first of a block partition, every rank of a cyclic one) that frame cannot be filtered before the level's
+    // exchange, and the interior frames behind it still leave early.
+    std::vector<char> filtered(nOwned, 0), saved(nOwned, 0);
     for (int k = 0; k < nOwned; ++k) {
       store.wait(k, level);  // this frame's level is decoded (the pool is busy with later frames / finer levels)
       Timer t;
@@ -373,17 +376,25 @@ int main(int argc, char** argv) {
       // (only at the two finest levels: above them a level's files are a few MB, and waiting for the GPU once per
       // frame instead of once per level costs more than they do)
       if (so.do_temporal_filter && level <= J.levelEnd + 1) {
-        const int ready = nFiltered;  // filtered in an earlier iteration: their kernels ran before this frame's compute
-        while (nFiltered < nOwned) {
-          const int rc = derp_seq_level_filter_frame(seq, level, owned[nFiltered]);
-          if (rc == 2) {
-            break;
+        std::vector<int> ready;  // filtered in an earlier iteration: their kernels ran before this frame's compute
+        for (int j = 0; j < nOwned; ++j) {
+          if (filtered[j] && !saved[j]) {
+            ready.push_back(j);
           }
-          DERP_OK(ctx, rc);
-          ++nFiltered;
         }
-        for (; nSaved < ready; ++nSaved) {
-          writer.save_seq(seq, owned[nSaved], level, zero_pad(owned[nSaved]), dirs, level == J.levelEnd, true);
+        for (int j = 0; j <= k; ++j) {  // a frame's window never reaches past frame j + radius: later ones cannot be ready
+          if (!filtered[j]) {
+            const int rc = derp_seq_level_filter_frame(seq, level, owned[j]);
+            if (rc == 2) {
+              continue;  // its window is not complete yet (a later frame, or a halo frame the exchange brings)
+            }
+            DERP_OK(ctx, rc);
+            filtered[j] = 1;
+          }
+        }
+        for (int j : ready) {
+          writer.save_seq(seq, owned[j], level, zero_pad(owned[j]), dirs, level == J.levelEnd, true);
+          saved[j] = 1;
         }
       }
     }
@@ -410,9 +421,11 @@ int main(int argc, char** argv) {
       DERP_OK(ctx, derp_synchronize(ctx));
       tCompute += t.s();
     }
-    for (int k = nSaved; k < nOwned; ++k) {
-      // PNG only at the finest level: the pipeline forces PFM above it (pipeline.py:366-369)
-      writer.save_seq(seq, owned[k], level, zero_pad(owned[k]), dirs, level == J.levelEnd);
+    for (int k = 0; k < nOwned; ++k) {
+      if (!saved[k]) {
+        // PNG only at the finest level: the pipeline forces PFM above it (pipeline.py:366-369)
+        writer.save_seq(seq, owned[k], level, zero_pad(owned[k]), dirs, level == J.levelEnd);
+      }
     }
     LOG_INFO(fmt("-- level %d: %.3fs (waited for decode %.3fs, input hand-over %.3fs, result downloads incl. waiting for "
                  "the GPU %.3fs, waited for a free download plane %.3fs)", level, total.s() - lv0, store.waited - dec0,

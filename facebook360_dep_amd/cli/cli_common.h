@@ -705,8 +705,21 @@ inline void write_png(const fs::path& path, const uint16_t* px, int w, int h, in
 
 // cv_util::loadImage<Vec3w> (CvUtil.h:196-284): IMREAD_UNCHANGED -> 16U (8-bit x257) -> BGR
 // into a caller buffer of expectW x expectH x 3 (pinned staging memory of the CLI's I/O pipeline)
+// convertTo(CV_8U / CV_16U, scale) of a CV_32F image (CvUtil.h:196-207): saturate_cast of the value rounded to the
+// nearest integer, ties to even (cvRound); NaN -> 0 like cvRound's conversion of an invalid value saturated
+inline unsigned float_to_uint_sat(float v, float scale, unsigned maxv) {
+  const double r = nearbyint((double)v * (double)scale);
+  return !(r > 0) ? 0u : r >= (double)maxv ? maxv : (unsigned)r;
+}
 inline void raster_to_bgr16(const Png& p, const fs::path& path, uint16_t* out) {
-  CHECK_MSG(p.bitdepth == 8 || p.bitdepth == 16, "cannot use a float image as colour: " + path.string());
+  if (p.bitdepth == 32) {  // a float image (one channel): convertTo(CV_16U, 65535 / 1.0), COLOR_GRAY2BGR
+    CHECK_MSG(p.channels == 1 && p.f32.size() == (size_t)p.w * p.h, "unsupported float image as colour: " + path.string());
+    for (size_t i = 0; i < p.f32.size(); ++i) {
+      out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = (uint16_t)float_to_uint_sat(p.f32[i], 65535.0f, 65535u);
+    }
+    return;
+  }
+  CHECK_MSG(p.bitdepth == 8 || p.bitdepth == 16, "unsupported bit depth of a colour image: " + path.string());
   const int mul = p.bitdepth == 8 ? 257 : 1;  // convertTo(CV_16U, 65535 / 255)
   const size_t n = (size_t)p.w * p.h;
   for (size_t i = 0; i < n; ++i) {
@@ -751,10 +764,17 @@ inline std::vector<uint16_t> load_color_bgr16(const fs::path& path, int& w, int&
 // when the GREEN channel passed the threshold (G alone rounds to 1, B + R together to 0)
 inline std::vector<uint8_t> load_mask(const fs::path& path, int& w, int& h) {
   const Png p = read_raster(path);
-  CHECK_MSG(p.bitdepth == 8 || p.bitdepth == 16, "cannot use a float image as a mask: " + path.string());
   w = p.w;
   h = p.h;
   std::vector<uint8_t> out((size_t)w * h);
+  if (p.bitdepth == 32) {  // a float image (one channel): convertTo(CV_8U, 255 / 1.0), then the threshold
+    CHECK_MSG(p.channels == 1 && p.f32.size() == out.size(), "unsupported float image as a mask: " + path.string());
+    for (size_t i = 0; i < out.size(); ++i) {
+      out[i] = float_to_uint_sat(p.f32[i], 255.0f, 255u) > 127;
+    }
+    return out;
+  }
+  CHECK_MSG(p.bitdepth == 8 || p.bitdepth == 16, "unsupported bit depth of a mask: " + path.string());
   const int pick = p.channels >= 3 ? 1 : 0;
   for (size_t i = 0; i < out.size(); ++i) {
     unsigned v = p.px[(size_t)p.channels * i + pick];
@@ -1225,6 +1245,17 @@ struct IoBatch {
   bool done() {
     std::lock_guard<std::mutex> lk(mu);
     return pending == 0;
+  }
+  // the first error any finished job left, raised on the calling thread without waiting for the rest
+  void raise_if_failed() {
+    std::string err;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      err = error;
+    }
+    if (!err.empty()) {
+      LOG_FATAL(err);
+    }
   }
   void wait() {
     std::string err;

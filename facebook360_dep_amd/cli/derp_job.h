@@ -697,6 +697,7 @@ struct LevelWriter {
       });
       ring[got].writers = writers;
     }
+    ringBatch.raise_if_failed();  // a write job of an earlier frame failed: stop here, not after the whole level
     waited += t.s();
     Arena& A = ring[got].mem;
     if (A.bytes < bytes) {
@@ -749,6 +750,14 @@ struct LevelWriter {
         bases.push_back(DerpJob::levelDir(dir, level) / J.rigDst[d].id);
       }
       ringBatch.add(pool, [=] {
+        // the slot goes back on EVERY exit path: a write that fails (disk full, unwritable output) throws, the batch
+        // keeps the message, and ring_acquire / finish() on the host thread turn it into the fatal exit — a slot
+        // that stayed taken would park the host thread in ring_acquire for ever instead
+        struct Release {
+          LevelWriter* w;
+          int slot;
+          ~Release() { w->ring_release(slot); }
+        } release{this, slot};
         for (const auto& base : bases) {
           write_pfm(base / (frameName + ".pfm"), disp, w, h);
           if (png) {
@@ -758,7 +767,6 @@ struct LevelWriter {
             write_exr_f32(base / (frameName + ".exr"), disp, w, h);
           }
         }
-        ring_release(slot);
       }, 1);
     }
   }

@@ -1540,11 +1540,13 @@ inline Raster decode_tiff(const Bytes& b) {
   need(offs && counts, "TIFF without strip / tile offsets");
   const int across = (W + tw - 1) / tw, down = (H + th - 1) / th;
   const int planes = planar == 2 ? spp : 1, chunkSpp = planar == 2 ? 1 : spp;
-  need((int64_t)across * down * planes <= (int64_t)offs->count && counts->count >= offs->count, "TIFF with too few strips / tiles");
+  const int64_t nChunks = (int64_t)across * down * planes;  // bounded before any 32-bit arithmetic uses it
+  need(nChunks <= INT32_MAX / 2, "corrupt TIFF: too many strips / tiles");
+  need(nChunks <= (int64_t)offs->count && counts->count >= offs->count, "TIFF with too few strips / tiles");
   const int bytesPer = bits / 8;
   {
     size_t present = 0;
-    for (uint32_t i = 0; i < (uint32_t)(across * down * planes); ++i) {
+    for (uint32_t i = 0; i < (uint32_t)nChunks; ++i) {
       present += f.value(*counts, i);
     }
     need(present <= b.n, "TIFF strips / tiles larger than the file");
@@ -1716,12 +1718,15 @@ inline Raster decode_bmp(const Bytes& b) {
   img.w = info.w;
   img.h = info.h;
   img.bitdepth = 8;
-  const unsigned char* pal = b.d + 14 + info.headerSize;
+  // the palette as the pixels index it: 256 entries, the file's biClrUsed of them, zeros beyond (grfmt_bmp.cpp reads
+  // the entries into a zero-filled 256-entry table) — a pixel value above biClrUsed must not reach past the file
+  unsigned char pal[256 * 4] = {0};
   bool grayPalette = true;
   if (info.bpp == 8) {
     uint32_t used = le32(b.d + 46);
     used = used == 0 || used > 256 ? 256 : used;
-    b.span(14 + info.headerSize, (size_t)used * 4, "truncated BMP palette");
+    b.span(14 + (size_t)info.headerSize, (size_t)used * 4, "truncated BMP palette");
+    memcpy(pal, b.d + 14 + info.headerSize, (size_t)used * 4);
     for (uint32_t i = 0; i < used; ++i) {  // grfmt_bmp.cpp IsColorPalette: gray only when every entry has b == g == r
       grayPalette = grayPalette && pal[4 * i] == pal[4 * i + 1] && pal[4 * i] == pal[4 * i + 2];
     }

@@ -263,8 +263,9 @@ def load_color_u16(path):
     """cv_util::loadImage<Vec3w> (CvUtil.h:226-284): cv::imread(IMREAD_UNCHANGED) of any format it reads, depth -> 16U
     (x257 from 8-bit), channels -> BGR (gray replicated, alpha dropped)."""
     a = read_image(path)
-    if a.dtype == np.float32:
-        raise ValueError("cannot use a float image as colour: %s" % path)
+    if a.dtype == np.float32:  # convertTo(CV_16U, 65535 / 1.0): saturate_cast of the value rounded half to even
+        a = np.clip(np.rint(np.nan_to_num(a.astype(np.float64), nan=0.0) * 65535.0), 0, 65535).astype(np.uint16)
+        a = a.reshape(a.shape[0], a.shape[1])
     if a.dtype == np.uint8:
         a = a.astype(np.uint16) * 257
     if a.ndim == 2:
@@ -277,8 +278,9 @@ def load_mask(path):
     COLOR_BGR[A]2GRAY of the 0 / 1 values, whose rounded fixed-point weights give 1 exactly when the GREEN channel's bit
     is set (G alone rounds to 1, B + R together to 0)."""
     a = read_image(path)
-    if a.dtype == np.float32:
-        raise ValueError("cannot use a float image as a mask: %s" % path)
+    if a.dtype == np.float32:  # convertTo(CV_8U, 255 / 1.0), then the threshold
+        a = np.clip(np.rint(np.nan_to_num(a.astype(np.float64), nan=0.0) * 255.0), 0, 255).astype(np.uint8)
+        a = a.reshape(a.shape[0], a.shape[1])
     if a.ndim == 3:
         a = a[..., 1]
     if a.dtype == np.uint16:

@@ -78,6 +78,25 @@ def test_bench_two_ranks_one_gpu(built):
     assert len(out["halo_transport_per_rank"]) == 2 and len(set(out["halo_transport_per_rank"])) == 1
 
 
+def test_bench_plain_command_shards_itself_or_fails(built):
+    """The driver's command is `python bench.py --gpus N` with no launcher around it: bench.py must start the N ranks
+    itself (here: two ranks on the one GPU, DERP_BENCH_SINGLE_DEVICE) and print n_gpus = N — and on a box with fewer
+    than N devices it must FAIL, never print a 1-GPU line for a --gpus N request."""
+    import torch
+
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "small",
+           "--frames", "4", "--backend", "gloo", "--synth-device", "cpu"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, DERP_BENCH_SINGLE_DEVICE="1"))
+    out = _line(p)
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "frames x2"
+    assert out["result_crc"] == _oracle_crc_small(4)
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")], p.stdout[-500:]
+        assert "refusing" in p.stderr
+
+
 @pytest.mark.parametrize("world,partition", [(2, 0), (4, 0), (4, 1), (8, 0)])
 def test_result_crc_of_emulated_ranks_equals_one_rank(built, world, partition):
     """bench.py's workload shape (`small` rig, temporal filter) on `world` ranks emulated on one GPU: the

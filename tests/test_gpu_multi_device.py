@@ -155,6 +155,19 @@ def test_bench_two_gpus_over_rccl(built):
     assert out["result_crc"] == {str(t): "%08x" % v for t, v in seq.result_crc().items()}
 
 
+@needs_two
+def test_bench_plain_command_two_gpus(built):
+    """(e): `python bench.py --gpus 2` with no launcher — what the driver's scaling run types — starts its own two
+    ranks, one per device, over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--config", "small", "--frames", "4", "--synth-device", "cpu"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["halo_transport_per_rank"] == ["rccl", "rccl"], out["halo_transport_per_rank"]
+
+
 def test_multi_device_tests_are_collected_and_skip_cleanly_on_one_gpu():
     """Keeps the file honest on a 1-GPU box: the gate is the device count, nothing else."""
     assert _device_count() >= 1

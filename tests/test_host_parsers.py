@@ -75,3 +75,23 @@ def test_exr_and_pfm(harness, tmp_path):
         assert p.returncode == 1 and "pfm" in p.stderr, (header, p.stderr[-300:])
     open(path, "wb").write(b"Pf\n5 5\n-1.0\n" + b"\0" * 100)
     assert run(harness, "pfm", path).stdout.split() == ["ok", "5", "5"]
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` without a launcher starts its own N ranks; with fewer than N devices (none in the CPU
+    container) it must exit non-zero and print no JSON line — a `--gpus 8` request must never yield an `n_gpus: 1`
+    line. A launcher whose WORLD_SIZE disagrees with --gpus is refused the same way."""
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DERP_BENCH_SINGLE_DEVICE")}
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode != 0 and "refusing" in p.stderr and "{" not in p.stdout
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--config", "tiny"],
+                       capture_output=True, text=True, timeout=300, env=dict(env, RANK="0", WORLD_SIZE="1"))
+    assert p.returncode != 0 and "does not match WORLD_SIZE" in p.stderr and "{" not in p.stdout

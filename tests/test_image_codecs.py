@@ -540,6 +540,17 @@ def test_bmp_and_pnm(harness, tmp_path):
         Image.fromarray(rgb).save(path)
         got, _, _ = decode(harness, path)
         assert np.array_equal(got, rgb)
+    # a palette shorter than the pixel values reach (biClrUsed = 2, pixel 255): the missing entries read as zeros
+    # (grfmt_bmp.cpp fills a 256-entry table), never as the bytes behind the file (heap overflow under ASan)
+    w_, h_ = w, h
+    w, h = 1, 1
+    open(path, "wb").write(bmp(8, False, [(9, 9, 9), (200, 200, 200)], np.asarray([[255]], dtype=np.uint8)))
+    got, _, _ = decode(harness, path)
+    assert got.shape[:2] == (1, 1) and int(got.ravel()[0]) == 0
+    open(path, "wb").write(bmp(8, False, [(9, 9, 9), (200, 200, 200)], np.asarray([[1]], dtype=np.uint8)))
+    got, _, _ = decode(harness, path)
+    assert int(got.ravel()[0]) == 200
+    w, h = w_, h_
 
     path = str(tmp_path / "t.pnm")
     for maxv, dt in ((255, ">u1"), (65535, ">u2"), (1000, ">u2"), (100, ">u1")):
@@ -635,6 +646,14 @@ def test_python_host_reads_the_same_through_the_c_abi(tmp_path):
         if Image is not None and a.dtype == np.uint8 and a.ndim == 3:
             ref = np.asarray(Image.open(path))
             assert np.array_equal(ref, a[..., [2, 1, 0] + ([3] if a.shape[2] == 4 else [])])
+    # a float image as colour / mask: cv_util::convertImage (CvUtil.h:196-262) scales CV_32F by 65535 / 255 with
+    # saturate_cast's round-half-even and then goes on as for an integer image
+    f = np.asarray([[0.0, 0.25, 0.5, 1.0, 1.5, -0.2, 127.5 / 255.0, 128.4 / 255.0]], dtype=np.float32)
+    dio.write_tiff(path, f)
+    col = dio.load_color_u16(path)
+    assert col.shape == (1, 8, 3) and col.dtype == np.uint16
+    assert col[0, :, 0].tolist() == [0, 16384, 32768, 65535, 65535, 0, 32768, 32999] and np.array_equal(col[..., 0], col[..., 2])
+    assert dio.load_mask(path)[0].tolist() == [0, 0, 1, 1, 1, 0, 1, 1]
     open(path, "wb").write(b"RIFF\x10\0\0\0WEBPVP8 ")
     with pytest.raises(ValueError, match="webp"):
         dio.read_image(path)
