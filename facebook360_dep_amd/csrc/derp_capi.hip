@@ -126,6 +126,7 @@ struct derp_ctx {
   DevBuf temporalCarry;  // accumulators of a temporal window longer than one launch holds
   DevBuf tileSeen;       // k_reproject_bias: per (table, tile) whether any map position is valid
   int colorTablesCleanLevel = -1;  // level whose colour / bias tables were written in full since its warps were built
+  DevBuf projColorT;  // projColor again in 4x4-texel tiles: the random-proposal kernel's copy (DERP_RANDOM_TILED)
   DevBuf projWarp, projColor, projBias, projWarpInv, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
   DevBuf rayDir, behind;  // per destination pixel: ray direction [3][D][n] f64, sources facing away [D][n] (k_pixel_rays)
   int warpCachedLevel = -1;
@@ -143,6 +144,11 @@ struct derp_ctx {
 
   bool profiling = false;
   bool noMemo = false;  // DERP_NO_MEMO (developer switch), read once in derp_create
+  // waves per SIMD of the random-proposal / ping-pong kernels (0 = what their registers allow, three): a launch can ask
+  // for fewer by reserving more LDS per (one-wave) block — the kernels that miss L2 trade latency hiding against the
+  // working set their resident waves spread over it, and the right answer depends on the level size (DERP_RANDOM_WAVES,
+  // DERP_PP_WAVES: developer A/B; randomWavesBigLevel: the policy, see run_random_proposals)
+  int randomWaves = 0, ppWaves = 0;
   bool noTemporalTile = false;  // DERP_NO_TEMPORAL_TILE (developer A/B: the direct form of the temporal filter)
   bool noBlankSkip = false;     // DERP_NO_BLANK_SKIP (developer A/B: every frame rewrites the blank tiles of the colour tables)
   std::vector<TimedSpan> spans;
@@ -262,6 +268,7 @@ LevelView make_view(derp_ctx* c, int stage, int dst0, int nd) {
   V.projWarp = c->projWarp.as<float2>();
   V.projColor = c->projColor.as<ushort4>();
   V.projBias = c->projBias.as<ushort4>();
+  V.projColorT = c->projColorT.as<ushort4>();
   V.disparity = c->disparity.as<float>();
   V.cost = c->cost.as<float>();
   V.confidence = c->confidence.as<float>();
@@ -508,9 +515,28 @@ int upsample_masked_dev(derp_ctx* c, const float* in, const uint8_t* mask, int s
   return 0;
 }
 
-size_t table_bytes_per_dst(const derp_ctx* c, int W, int H) {
+// Stored inverse warps (projWarpInv) are needed only for sources that are not the own source of a destination of the
+// same batch: everywhere else projWarpInv(d, s) is projWarp(ds, own(d)) (derp_kernels.h, batch_dst_of_source).
+bool batch_needs_inverse_warps(const derp_ctx* c, int dst0, int nd) {
+  if (DERP_NO_WARP_IDENTITY) {
+    return true;
+  }
+  std::vector<char> covered(c->S, 0);
+  for (int d = dst0; d < dst0 + nd; ++d) {
+    covered[c->dst2srcH[d]] = 1;
+  }
+  for (int s = 0; s < c->S; ++s) {
+    if (!covered[s]) {
+      return true;
+    }
+  }
+  return false;
+}
+
+size_t table_bytes_per_dst(const derp_ctx* c, int W, int H, bool withInverse) {
   const size_t wp = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW), cp = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC);
-  return (size_t)(c->S - 1) * (wp * sizeof(float2) + 2 * cp * sizeof(ushort4) + (size_t)W * H * sizeof(float2));
+  return (size_t)(c->S - 1) * (wp * sizeof(float2) + 2 * cp * sizeof(ushort4) + (withInverse ? (size_t)W * H * sizeof(float2) : 0) +
+                               (DERP_RANDOM_TILED ? tiled_plane(W, H) * sizeof(ushort4) : 0));
 }
 
 int compute_fov_and_masks(derp_ctx* c, int level) {
@@ -545,9 +571,12 @@ int build_warp(derp_ctx* c, int dst0, int nd) {
                      c->behind.as<unsigned>());
   KCHECK(c);
   c->colorTablesCleanLevel = -1;  // new warps (another level, batch or rig state): the colour tables must be rewritten in full
-  // ... and the inverse warps reprojectColors reads (projWarpInv, PyramidLevel.h:46-51)
-  hipLaunchKernelGGL(k_proj_warp_inv, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->projWarpInv.as<float2>());
-  KCHECK(c);
+  // ... and the inverse warps reprojectColors reads (projWarpInv, PyramidLevel.h:46-51) — those that are not a
+  // projWarp table of this batch already (all of them are when every source is a destination of the batch)
+  if (batch_needs_inverse_warps(c, dst0, nd)) {
+    hipLaunchKernelGGL(k_proj_warp_inv, grid2d(V.W, V.H, nd, kBlk2d), kBlk2d, 0, c->stream, V, c->projWarpInv.as<float2>());
+    KCHECK(c);
+  }
   return 0;
 }
 
@@ -562,7 +591,8 @@ int build_color_tables(derp_ctx* c, int dst0, int nd) {
   // level frame after frame) skips the tiles no source pixel maps into — they still hold their zeros
   const int skipBlank = c->colorTablesCleanLevel == L && nd == c->D && !c->noBlankSkip;
   hipLaunchKernelGGL(k_reproject_bias, grid, dim3(256), 0, c->stream, V, c->projWarpInv.as<float2>(),
-                     c->projColor.as<ushort4>(), c->projBias.as<ushort4>(), c->tileSeen.as<uint8_t>(), skipBlank);
+                     c->projColor.as<ushort4>(), c->projBias.as<ushort4>(), c->projColorT.as<ushort4>(),
+                     c->tileSeen.as<uint8_t>(), skipBlank);
   KCHECK(c);
   c->colorTablesCleanLevel = nd == c->D ? L : -1;
   return 0;
@@ -578,6 +608,13 @@ int tiles_of(int W, int H, int& tilesX) {
 constexpr size_t kCostLdsPerSrc = (size_t)DERP_COST_BLOCK * sizeof(SsdPair);
 int round8(int n) {
   return (n + 7) / 8 * 8;
+}
+// dynamic LDS of a one-wave block such that at most `waves` blocks per SIMD (4 x waves per CU) fit a CU's 160 KB
+size_t lds_for_waves(size_t needed, int waves) {
+  if (waves <= 0 || waves >= 3) {
+    return needed;
+  }
+  return std::max(needed, (size_t)(160 * 1024 / (4 * waves + 1) + 256));
 }
 
 int run_brute_force(derp_ctx* c, int dst0, int nd) {
@@ -619,7 +656,7 @@ int run_random_proposals(derp_ctx* c, int dst0, int nd) {
   }
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
+  const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->randomWaves);
   hipLaunchKernelGGL(k_random_proposals, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->rank.as<int>(),
                      tilesX, tiles);
   KCHECK(c);
@@ -637,7 +674,7 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   HIPCHK(c, hipMemsetAsync(c->changed.as<uint8_t>() + (size_t)dst0 * n, 1, n * nd, c->stream));
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = kCostLdsPerSrc * (size_t)(c->S);
+  const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->ppWaves);
   for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
     hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->changed.as<uint8_t>(),
                        c->dispRes.as<float>(), c->costRes.as<float>(), tilesX,
@@ -804,24 +841,33 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   }
   // table budget -> dst batch. When the buffers already hold every destination's tables of this level (the
   // steady state of a sequence: same levels frame after frame) there is nothing to ask the runtime.
-  const size_t per = table_bytes_per_dst(c, W, H);
+  // (the inverse-warp table only exists when a batch holds a source that is not one of its destinations)
+  const bool invAll = batch_needs_inverse_warps(c, 0, c->D);
+  size_t per = table_bytes_per_dst(c, W, H, invAll);
   int DB = c->D;
+  bool needInv = invAll;
   {
     const size_t wpAll = (size_t)(W + 2 * kPadW) * (H + 2 * kPadW) * (c->S - 1) * c->D * sizeof(float2);
     const size_t cpAll = (size_t)(W + 2 * kPadC) * (H + 2 * kPadC) * (c->S - 1) * c->D * sizeof(ushort4);
     const size_t ipAll = (size_t)W * H * (c->S - 1) * c->D * sizeof(float2);
     const bool resident = c->projWarp.bytes >= wpAll && c->projColor.bytes >= cpAll && c->projBias.bytes >= cpAll &&
-        c->projWarpInv.bytes >= ipAll && !getenv("DERP_TABLE_BUDGET_GB");
+        (!invAll || c->projWarpInv.bytes >= ipAll) && !getenv("DERP_TABLE_BUDGET_GB") &&
+        (!DERP_RANDOM_TILED || c->projColorT.bytes >= tiled_plane(W, H) * (c->S - 1) * c->D * sizeof(ushort4));
     if (!resident) {
       size_t freeB = 0, totalB = 0;
       HIPCHK(c, hipMemGetInfo(&freeB, &totalB));
-      size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes + c->projWarpInv.bytes;
+      size_t budget = freeB + c->projWarp.bytes + c->projColor.bytes + c->projBias.bytes + c->projWarpInv.bytes + c->projColorT.bytes;
       if (const char* e = getenv("DERP_TABLE_BUDGET_GB")) {
         budget = std::min<size_t>(budget, (size_t)(atof(e) * (1ull << 30)));
       } else {
         budget = (size_t)(budget * 0.85);
       }
       DB = (int)std::min<size_t>((size_t)c->D, budget / std::max<size_t>(per, 1));
+      if (DB < c->D && !needInv) {  // batches: the sources outside a batch need stored inverse warps
+        needInv = true;
+        per = table_bytes_per_dst(c, W, H, true);
+        DB = (int)std::min<size_t>((size_t)c->D, budget / std::max<size_t>(per, 1));
+      }
       if (DB < 1) {
         return fail(c, "projection tables for one destination (%zu bytes) exceed the table budget (%zu bytes)", per, budget);
       }
@@ -835,7 +881,12 @@ int level_begin(derp_ctx* c, int level, bool buildAllTables) {
   ALLOC(c, c->projWarp, (size_t)DB * (c->S - 1) * wp * sizeof(float2));
   ALLOC(c, c->projColor, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
   ALLOC(c, c->projBias, (size_t)DB * (c->S - 1) * cp * sizeof(ushort4));
-  ALLOC(c, c->projWarpInv, (size_t)DB * (c->S - 1) * n * sizeof(float2));
+  if (needInv) {
+    ALLOC(c, c->projWarpInv, (size_t)DB * (c->S - 1) * n * sizeof(float2));
+  }
+  if (DERP_RANDOM_TILED) {
+    ALLOC(c, c->projColorT, (size_t)DB * (c->S - 1) * tiled_plane(W, H) * sizeof(ushort4));
+  }
   c->tablesValid = false;
   c->randomRanThisLevel = false;
   if (buildAllTables) {
@@ -1062,6 +1113,12 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
     c->xcdRotate = atoi(e);
   }
   c->noMemo = getenv("DERP_NO_MEMO") != nullptr;
+  if (const char* e = getenv("DERP_RANDOM_WAVES")) {
+    c->randomWaves = atoi(e);
+  }
+  if (const char* e = getenv("DERP_PP_WAVES")) {
+    c->ppWaves = atoi(e);
+  }
   c->noTemporalTile = getenv("DERP_NO_TEMPORAL_TILE") != nullptr;
   c->noBlankSkip = getenv("DERP_NO_BLANK_SKIP") != nullptr;
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -1129,7 +1186,7 @@ void derp_destroy(derp_ctx* c) {
   c->devMask.release();
   for (DevBuf* b : {&c->camsSrc, &c->camsDst, &c->dst2src, &c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd,
                     &c->disparity, &c->cost, &c->confidence, &c->dispRes, &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount,
-                    &c->projWarp, &c->projColor, &c->projBias, &c->projWarpInv, &c->temporalCarry, &c->tileSeen, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
+                    &c->projWarp, &c->projColor, &c->projBias, &c->projColorT, &c->projWarpInv, &c->temporalCarry, &c->tileSeen, &c->rayDir, &c->behind, &c->bruteCost, &c->bruteConf, &c->lanczosTmp,
                     &c->staging, &c->stagingB, &c->counters, &c->spiral}) {
     b->release();
   }

@@ -72,6 +72,39 @@ namespace derp {
 #ifndef DERP_COST_SSD_SCALAR
 #define DERP_COST_SSD_SCALAR 0
 #endif
+// random proposals, round 5: every lane of a wave gathers at its own place on its epipolar curve; the kernel's
+// gathers miss L2 (66 % hits, 141 GB through the memory-side counters per level-0 launch at config 2 in round 4).
+//  DERP_RANDOM_BLOCK_BIAS (on)  srcBias = bilinear sample of projBias = 2x2 taps of the 3x3 box of projColor — which are
+//                        sums over exactly the 4x4 block already in registers: the two projBias loads (2.1 cache lines
+//                        per pair, and a third of the kernel's table footprint) become ~110 VALU instructions. Exact:
+//                        the box is an integer sum < 2^24 (exact in fp32) and trunc((s + 4) * fl(1/9)) == (s + 4) / 9
+//                        for every s <= 9 * 65535 (checked exhaustively, tests/test_abi.py). Taps on the image's first /
+//                        last row or column (BORDER_REFLECT_101 there, a replicated ring in the table) load projBias.
+//                        Measured (profiles/r05_kernel_variants.txt): 142 -> 53 GB per launch, L2 hits 66 -> 82 %,
+//                        config 4's random proposals 485 -> 367 ms.
+//  DERP_RANDOM_TILED (off: measured, rejected)  the 4x4 block from a second copy of projColor stored in 4x4-texel tiles
+//                        of one 128-byte line each (k_reproject_bias writes both): 3.06 lines per block instead of
+//                        4.75, but sixteen 8-byte loads instead of eight 16-byte ones. 53 -> 48 GB, and slower: +2 %
+//                        at config 2; at config 4 the copy costs a third destination batch (+25 % table bytes) and the
+//                        tiled stores +25 ms of k_reproject_bias.
+#ifndef DERP_RANDOM_TILED
+#define DERP_RANDOM_TILED 0
+#endif
+#ifndef DERP_RANDOM_BLOCK_BIAS
+#define DERP_RANDOM_BLOCK_BIAS 1
+#endif
+// ping-pong: read the pixel's ray direction from its table per candidate instead of keeping it (in scratch) across the loop
+#ifndef DERP_PP_RELOAD_RAY
+#define DERP_PP_RELOAD_RAY 1
+#endif
+#ifndef DERP_RANDOM_RECONVERT
+#define DERP_RANDOM_RECONVERT 1
+#endif
+// developer A/B: 1 = compute and store every inverse warp (round 4) instead of reading projWarp(ds, own) where source s
+// is a destination of the batch
+#ifndef DERP_NO_WARP_IDENTITY
+#define DERP_NO_WARP_IDENTITY 0
+#endif
 static constexpr int kPadW = 1;   // ring of projWarp
 static constexpr int kPadC = 2;   // ring of projColor / projBias
 static constexpr int kMaxSrc = 32;
@@ -104,6 +137,7 @@ struct LevelView {
   const float2* projWarp;     // [D][S-1] padded
   const ushort4* projColor;
   const ushort4* projBias;
+  const ushort4* projColorT;  // projColor again in 4x4-texel tiles (tile_index); null = not kept
   // per dst (global index)
   float* disparity;           // [Dtotal][H*W]
   float* cost;
@@ -119,6 +153,17 @@ __device__ __forceinline__ size_t warp_plane(const LevelView& V) {
 }
 __device__ __forceinline__ size_t color_plane(const LevelView& V) {
   return (size_t)(V.W + 2 * kPadC) * (V.H + 2 * kPadC);
+}
+// projColorT: the padded (W + 4) x (H + 4) texel grid of a projColor plane in 4x4-texel tiles, one 128-byte line each
+__host__ __device__ __forceinline__ int tiled_tiles_x(int W) {
+  return (W + 2 * kPadC + 3) >> 2;
+}
+__host__ __device__ __forceinline__ size_t tiled_plane(int W, int H) {
+  return (size_t)tiled_tiles_x(W) * (size_t)((H + 2 * kPadC + 3) >> 2) * 16;
+}
+// texel index of padded coordinates (ox, oy)
+__device__ __forceinline__ size_t tiled_index(int tilesX, int ox, int oy) {
+  return ((size_t)(oy >> 2) * tilesX + (ox >> 2)) * 16 + (size_t)((oy & 3) * 4 + (ox & 3));
 }
 __device__ __forceinline__ int slot(int s, int own) {
   return s < own ? s : s - 1;
@@ -221,6 +266,58 @@ struct SsdTexels {
   u4a8 raw[4][2];
   u4a8 ba, bb;
 };
+// The random-proposal form: the block from the tiled copy `colT` (sixteen 8-byte loads: a texel row of the block can
+// straddle two tiles), the bias taps only for lanes whose taps touch the image's first / last row or column
+// (`border`; everywhere else ssd_arith sums them from the block).
+template <bool TILED, bool BLOCK_BIAS>
+__device__ __forceinline__ void ssd_issue_random(const LevelView& V, const ushort4* __restrict__ col, const ushort4* __restrict__ colT,
+                                                 const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc, SsdTexels& T,
+                                                 bool& border) {
+  const int pitch = V.W + 2 * kPadC;
+  const int xi = (int)roundf(xDstSrc), yi = (int)roundf(yDstSrc);
+  const unsigned off = ((unsigned)(yi - 2 + kPadC) * (unsigned)pitch + (unsigned)(xi - 2 + kPadC)) * 8u;
+  if constexpr (TILED) {
+    const unsigned xa = (unsigned)(xi - 2 + kPadC), ya = (unsigned)(yi - 2 + kPadC);
+    const unsigned rowTiles = (unsigned)tiled_tiles_x(V.W) * 128u;  // bytes of one row of tiles
+    const unsigned xr = xa & 3u, yr = ya & 3u;
+    const unsigned base0 = (ya >> 2) * rowTiles + (xa >> 2) * 128u + yr * 32u + xr * 8u;
+    const char* base = reinterpret_cast<const char*>(colT);
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      const unsigned ro = base0 + (unsigned)row * 32u + ((yr + (unsigned)row > 3u) ? rowTiles - 128u : 0u);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned o = ro + (unsigned)k * 8u + ((xr + (unsigned)k > 3u) ? 96u : 0u);
+        const u2 t = *reinterpret_cast<const u2*>(base + o);
+        if (k & 1) {
+          T.raw[row][k >> 1].z = t.x;
+          T.raw[row][k >> 1].w = t.y;
+        } else {
+          T.raw[row][k >> 1].x = t.x;
+          T.raw[row][k >> 1].y = t.y;
+        }
+      }
+    }
+  } else {
+    const char* base = reinterpret_cast<const char*>(col);
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+      T.raw[row][0] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u));
+      T.raw[row][1] = *reinterpret_cast<const u4a8*>(base + (off + (unsigned)row * (unsigned)pitch * 8u + 16u));
+    }
+  }
+  // bias taps (xi - 1 .. xi, yi - 1 .. yi): their 3x3 boxes lie inside the image — where the table's box (BORDER_REFLECT_101)
+  // and the block's (replicated ring) are the same nine texels — iff 2 <= xi <= W - 2 and 2 <= yi <= H - 2
+  border = !BLOCK_BIAS || xi < 2 || yi < 2 || xi > V.W - 2 || yi > V.H - 2;
+  T.ba = T.bb = (u4a8){0u, 0u, 0u, 0u};
+  if (border) {
+    const unsigned boff = off + ((unsigned)pitch + 1u) * 8u;  // (yi - 1, xi - 1)
+    const char* bbase = reinterpret_cast<const char*>(bia);
+    T.ba = *reinterpret_cast<const u4a8*>(bbase + boff);
+    T.bb = *reinterpret_cast<const u4a8*>(bbase + (boff + (unsigned)pitch * 8u));
+  }
+}
 __device__ __forceinline__ void ssd_issue(const LevelView& V, const ushort4* __restrict__ col,
                                           const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc, SsdTexels& T) {
   const int pitch = V.W + 2 * kPadC;
@@ -247,9 +344,9 @@ __device__ __forceinline__ void ssd_issue(const LevelView& V, const ushort4* __r
 
 // computeSSD (DerpUtil.cpp:126-162) for one source whose projected tables are `col` / `bias`; `T` holds the
 // texels ssd_issue requested for (xDstSrc, yDstSrc).
-template <bool SCALAR>
+template <bool SCALAR, bool BLOCK_BIAS = false>
 __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
-                                             const SsdTexels& T, float xDstSrc, float yDstSrc) {
+                                             const SsdTexels& T, float xDstSrc, float yDstSrc, bool border = true) {
 #ifdef DERP_ABLATE_NO_SSD
   return {xDstSrc * 1e-3f, yDstSrc * 1e-3f};
 #endif
@@ -267,7 +364,61 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
   const u4a8 (&raw)[4][2] = T.raw;
   // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
   float bias[3];
-  {
+  if constexpr (BLOCK_BIAS) {
+    // The four taps are 3x3 boxes of projColor (colorBias, DerpUtil.cpp:208-210: cv::blur on CV_16UC3 = exact integer sum,
+    // round(s / 9)) over block columns 0..2 / 1..3 and rows 0..2 / 1..3. Rows are visited 3, 2, 1, 0 so that the floats
+    // of rows 1 and 0 are the ones the block arithmetic below starts with; rows 2 and 3 are converted again there
+    // (their words pass through an empty asm below: kept live instead, the 48 floats cost the kernel its third wave).
+    const float xf = roundf(xDstSrc), yf = roundf(yDstSrc);
+    const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
+    const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
+    float top[3][2], bot[3][2];  // [channel][tap column]: rows 0..2 and rows 1..3
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+      const u4a8 a = raw[r][0], b = raw[r][1];
+      const float c[3][4] = {
+          {(float)(a.x & 0xffff), (float)(a.z & 0xffff), (float)(b.x & 0xffff), (float)(b.z & 0xffff)},
+          {(float)(a.x >> 16), (float)(a.z >> 16), (float)(b.x >> 16), (float)(b.z >> 16)},
+          {(float)(a.y & 0xffff), (float)(a.w & 0xffff), (float)(b.y & 0xffff), (float)(b.w & 0xffff)}};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float m = c[ch][1] + c[ch][2];
+        const float hA = m + c[ch][0], hB = m + c[ch][3];
+        if (r == 3) {
+          bot[ch][0] = hA + 4.0f;  // the + 4 of round(s / 9) = (s + 4) / 9, once per tap
+          bot[ch][1] = hB + 4.0f;
+        } else if (r == 2) {
+          bot[ch][0] += hA;
+          bot[ch][1] += hB;
+          top[ch][0] = hA + 4.0f;
+          top[ch][1] = hB + 4.0f;
+        } else if (r == 1) {
+          bot[ch][0] += hA;
+          bot[ch][1] += hB;
+          top[ch][0] += hA;
+          top[ch][1] += hB;
+        } else {
+          top[ch][0] += hA;
+          top[ch][1] += hB;
+        }
+      }
+    }
+    const float ninth = 1.0f / 9.0f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float t00 = __builtin_truncf(top[ch][0] * ninth), t01 = __builtin_truncf(top[ch][1] * ninth);
+      const float t10 = __builtin_truncf(bot[ch][0] * ninth), t11 = __builtin_truncf(bot[ch][1] * ninth);
+      bias[ch] = px.dstBias(ch) - bilerp_u16(t00, t01, t10, t11, w00, w01, w10, w11);
+    }
+    if (__ballot(border) != 0ull) {  // taps on the image's rim: the table's values (loaded by ssd_issue_random)
+      if (border) {
+        const u4a8 a = T.ba, b = T.bb;
+        bias[0] = px.dstBias(0) - bilerp_u16((float)(a.x & 0xffff), (float)(a.z & 0xffff), (float)(b.x & 0xffff), (float)(b.z & 0xffff), w00, w01, w10, w11);
+        bias[1] = px.dstBias(1) - bilerp_u16((float)(a.x >> 16), (float)(a.z >> 16), (float)(b.x >> 16), (float)(b.z >> 16), w00, w01, w10, w11);
+        bias[2] = px.dstBias(2) - bilerp_u16((float)(a.y & 0xffff), (float)(a.w & 0xffff), (float)(b.y & 0xffff), (float)(b.w & 0xffff), w00, w01, w10, w11);
+      }
+    }
+  } else {
     const float xf = roundf(xDstSrc), yf = roundf(yDstSrc);
     const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
     const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
@@ -308,10 +459,25 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     const float xw3[3] = {xwp.x, xwm, xwp.y};
     float d0s[3][3], d1s[3][3];  // [ix][iy]
     RowS lo, hi;
+    // (block bias: rows 2 and 3 were converted once already for the box sums; an opaque copy of their words makes the
+    // compiler convert them again here instead of keeping 24 more floats alive across the bias arithmetic)
+    auto again = [](const u4a8& v) {
+      u4a8 o = v;
+      if constexpr (BLOCK_BIAS && DERP_RANDOM_RECONVERT) {
+        unsigned a = v.x, b = v.y, c = v.z, d = v.w;
+        asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        o = (u4a8){a, b, c, d};
+      }
+      return o;
+    };
     unpack(raw[0][0], raw[0][1], lo);
 #pragma unroll
     for (int iy = 0; iy < 3; ++iy) {
-      unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+      if (iy >= 1) {
+        unpack(again(raw[iy + 1][0]), again(raw[iy + 1][1]), hi);
+      } else {
+        unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+      }
       const float omy = 1 - yw[iy];
 #pragma unroll
       for (int ix = 0; ix < 3; ++ix) {
@@ -483,12 +649,20 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
   const float scale = 1.0f / (65535.0f * 65535.0f);
   return {first * scale, second * scale};
 }
-template <bool SCALAR>
+// RANDOM: the random-proposal form (tiled block, bias from the block) when the context keeps the tiled copy `colT`
+template <bool SCALAR, bool RANDOM = false>
 __device__ __forceinline__ SsdPair compute_ssd(const LevelView& V, const PixCtx& px, const ushort4* __restrict__ col,
-                                               const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc) {
+                                               const ushort4* __restrict__ bia, float xDstSrc, float yDstSrc,
+                                               const ushort4* __restrict__ colT = nullptr) {
   SsdTexels T;
-  ssd_issue(V, col, bia, xDstSrc, yDstSrc, T);
-  return ssd_arith<SCALAR>(V, px, col, T, xDstSrc, yDstSrc);
+  if constexpr (RANDOM && (DERP_RANDOM_TILED || DERP_RANDOM_BLOCK_BIAS)) {
+    bool border;
+    ssd_issue_random<DERP_RANDOM_TILED != 0, DERP_RANDOM_BLOCK_BIAS != 0>(V, col, colT, bia, xDstSrc, yDstSrc, T, border);
+    return ssd_arith<SCALAR, DERP_RANDOM_BLOCK_BIAS != 0>(V, px, col, T, xDstSrc, yDstSrc, border);
+  } else {
+    ssd_issue(V, col, bia, xDstSrc, yDstSrc, T);
+    return ssd_arith<SCALAR>(V, px, col, T, xDstSrc, yDstSrc);
+  }
 }
 
 // Sources that cannot see this wave's pixels at ANY candidate depth: the pixel's ray O + t D, pushed through a
@@ -541,11 +715,23 @@ __device__ __forceinline__ unsigned behind_sources(const LevelView& V, int d, si
 // `cull` (wave-uniform, from behind_sources): slots of sources that no lane of the wave can see at any depth >=
 // kCullMinDepth; they are skipped without their cone test. 0 = test every source.
 // SCALAR: computeSSD's block arithmetic in plain instead of packed fp32 (ssd_arith).
-template <bool SCALAR = false>
+// RELOAD_RAY (ping-pong): the pixel's ray direction is read from the rayDir table at every call (pixel index `pix`)
+// instead of living in six registers across the candidate loop — where the allocator parked it in scratch (one store per
+// pixel, one load per candidate: 2.4 GB of scratch writes per level-0 launch at config 2, round 4). The opaque copy of
+// the index keeps the loads inside the loop.
+template <bool SCALAR = false, bool RANDOM = false, bool RELOAD_RAY = false>
 __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int own, const PixCtx& px, float disparity,
-                                               LdsPairs& pairs, unsigned& nPair, unsigned cull = 0) {
+                                               LdsPairs& pairs, unsigned& nPair, unsigned cull = 0, unsigned pix = 0,
+                                               unsigned* slots = nullptr) {
   const double depth = (double)(1.0f / disparity);
-  const D3 pWorld = {px.rayO.x + px.rayD.x * depth, px.rayO.y + px.rayD.y * depth, px.rayO.z + px.rayD.z * depth};
+  D3 rayD = px.rayD;
+  if constexpr (RELOAD_RAY) {
+    unsigned i = pix;
+    asm volatile("" : "+v"(i));
+    const double* rd = V.rayDir + (size_t)(V.dst0 + dl) * ((size_t)V.W * V.H);
+    rayD = {rd[i], rd[V.rayStride + i], rd[2 * V.rayStride + i]};
+  }
+  const D3 pWorld = {px.rayO.x + rayD.x * depth, px.rayO.y + rayD.y * depth, px.rayO.z + rayD.z * depth};
   const size_t wPlane = warp_plane(V), cPlane = color_plane(V);
   const int wPitch = V.W + 2 * kPadW;
   unsigned mask = 0, waveMask = 0;
@@ -553,6 +739,8 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
   cull = __builtin_amdgcn_readfirstlane(__ballot(!(depth >= kCullMinDepth)) != 0ull ? 0u : cull);
   const ushort4* colBase = V.projColor + (size_t)dl * (V.S - 1) * cPlane;
   const ushort4* biaBase = V.projBias + (size_t)dl * (V.S - 1) * cPlane;
+  const size_t tPlane = tiled_plane(V.W, V.H);
+  const ushort4* colTBase = RANDOM ? V.projColorT + (size_t)dl * (V.S - 1) * tPlane : nullptr;
   {
     bool pend = false;
     int pendSlot = 0;
@@ -617,6 +805,11 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
   }
   const int ssdCount = __popc(mask);
   nPair += ssdCount;
+#ifdef DERP_COUNT_UNION  // developer measurement: SSD iterations the WAVE walks (its lanes' union) per active lane
+  if (slots) {
+    *slots += __popc(__builtin_amdgcn_readfirstlane(waveMask));
+  }
+#endif
   int keep = 1;  // kMinOverlappingCams - 1
   if (ssdCount < keep) {
     return make_float2(3.402823466e+38f, 0.0f);
@@ -628,7 +821,8 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       const int t = __builtin_ctz(wm);
       if ((mask >> t) & 1) {
         const SsdPair e = pairs.get(t);
-        const SsdPair ssd = compute_ssd<SCALAR>(V, px, colBase + (size_t)t * cPlane, biaBase + (size_t)t * cPlane, e.first, e.second);
+        const SsdPair ssd = compute_ssd<SCALAR, RANDOM>(V, px, colBase + (size_t)t * cPlane, biaBase + (size_t)t * cPlane, e.first,
+                                                        e.second, RANDOM ? colTBase + (size_t)t * tPlane : nullptr);
         pairs.set(cnt, ssd);
         ++cnt;
       }
@@ -650,13 +844,16 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
 }
 
 // gather the per-pixel constants of computeCost: dst ray, 3x3 dst patch, dst bias, variance
+template <bool WITH_RAY = true>
 __device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, int x, int y, PixCtx& px) {
   const Cam& cd = V.camsDst[d];
   px.rayO = {cd.pos[0], cd.pos[1], cd.pos[2]};
   // the ray direction of the pixel centre (Camera::rig of p = ((x + .5) / W, (y + .5) / H): undistort's Newton
   // iteration, sin, cos) depends on the rig and the level size only: k_pixel_rays tabulates it with the warps
   const size_t n = (size_t)V.W * V.H;
-  {
+  if constexpr (!WITH_RAY) {
+    px.rayD = {0, 0, 0};  // compute_cost<.., RELOAD_RAY> reads it per call
+  } else {
     const size_t i = (size_t)d * n + (size_t)y * V.W + x;
     px.rayD = {V.rayDir[i], V.rayDir[V.rayStride + i], V.rayDir[2 * V.rayStride + i]};
   }
@@ -993,6 +1190,21 @@ __device__ __forceinline__ ushort4 remap_cubic_u16(const ushort4* __restrict__ i
   return make_ushort4((unsigned short)r0, (unsigned short)r1, (unsigned short)r2, 0);
 }
 
+// projWarpInv(d, s) = computeWarpDstToSrc(camDst d, camSrc s) and projWarp(d', s') = computeWarpDstToSrc(camSrc s',
+// camDst d') (Derp.cpp:969-970) are the SAME function of (camera the pixel grid belongs to, camera projected into):
+// when source s is itself a destination ds of the batch, projWarpInv(d, s) is projWarp(ds, own(d)) — already built,
+// by the same arithmetic (k_proj_warp and k_proj_warp_inv call the same rig_direction / sees with the same arguments).
+// Returns ds - dst0, or -1 when s is not the own source of a destination of this batch (a --cameras subset, or a
+// table-budget batch): only those inverse warps are computed and stored (k_proj_warp_inv).
+__device__ __forceinline__ int batch_dst_of_source(const LevelView& V, int s) {
+  for (int dl = 0; dl < V.D; ++dl) {
+    if (V.dst2src[V.dst0 + dl] == s) {
+      return dl;
+    }
+  }
+  return -1;
+}
+
 // The rig-space point a dst pixel's ray reaches at kNearInfinity (computeWarpDstToSrc, ImageUtil.cpp:142-167);
 // false outside the image circle.
 __device__ __forceinline__ bool dst_far_point(const LevelView& V, const Cam& cd, int x, int y, D3& rig) {
@@ -1034,7 +1246,8 @@ __global__ void k_proj_warp_inv(LevelView V, float2* __restrict__ warpInv) {
   const bool inside = dst_far_point(V, V.camsDst[d], x, y, rig);
   const size_t n = (size_t)V.W * V.H;
   for (int s = 0; s < V.S; ++s) {
-    if (s != own) {
+    // sources that are destinations of this batch: k_reproject_bias reads projWarp(ds, own) instead
+    if (s != own && (DERP_NO_WARP_IDENTITY || batch_dst_of_source(V, s) < 0)) {
       warpInv[((size_t)dl * (V.S - 1) + slot(s, own)) * n + (size_t)y * V.W + x] = warp_inv_of(V, V.camsSrc[s], inside, rig);
     }
   }
@@ -1058,7 +1271,8 @@ constexpr int kRbTile = 32, kRbPitch = kRbTile + 2, kRbCells = kRbPitch * kRbPit
 // (tile, source) combinations: the sources that face away from that part of the destination image).
 __global__ void __launch_bounds__(256)
     k_reproject_bias(LevelView V, const float2* __restrict__ warpInv, ushort4* __restrict__ projColor,
-                     ushort4* __restrict__ projBias, uint8_t* __restrict__ tileSeen, int skipBlank) {
+                     ushort4* __restrict__ projBias, ushort4* __restrict__ projColorT, uint8_t* __restrict__ tileSeen,
+                     int skipBlank) {
   __shared__ ushort4 tile[kRbCells];
   const int tab = blockIdx.z;  // dl * (S - 1) + slot
   uint8_t* seen = tileSeen + ((size_t)tab * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -1072,13 +1286,21 @@ __global__ void __launch_bounds__(256)
   const int OW = V.W + 2 * kPadC, OH = V.H + 2 * kPadC;
   const size_t plane = (size_t)OW * OH, n = (size_t)V.W * V.H;
   const ushort4* img = V.srcColor + (size_t)s * n;
+  // the inverse warp of this table: projWarp(ds, own) when source s is destination ds of the batch (the same
+  // function, see batch_dst_of_source; that table carries a 1-texel ring), the stored projWarpInv otherwise
   const float2* map = warpInv + (size_t)tab * n;
+  int mapPitch = V.W;
+  const int ds = DERP_NO_WARP_IDENTITY ? -1 : batch_dst_of_source(V, s);
+  if (ds >= 0) {
+    mapPitch = V.W + 2 * kPadW;
+    map = V.projWarp + ((size_t)ds * (V.S - 1) + slot(own, s)) * warp_plane(V) + (size_t)kPadW * mapPitch + kPadW;
+  }
   int any = 0;
   for (int k = threadIdx.x; k < kRbCells; k += 256) {
     const int ty = k / kRbPitch, tx = k - ty * kRbPitch;
     const int qx = x0 - 1 + tx, qy = y0 - 1 + ty;
     if (qx >= -1 && qx <= V.W && qy >= -1 && qy <= V.H) {
-      const float2 m = map[(size_t)reflect101(qy, V.H) * V.W + reflect101(qx, V.W)];
+      const float2 m = map[(size_t)reflect101(qy, V.H) * mapPitch + reflect101(qx, V.W)];
       // NaN map -> (-32768, -32768) in cv::remap's fixed point -> every tap outside -> constant border 0
       const bool valid = !(m.x != m.x);
       any |= valid;
@@ -1091,6 +1313,9 @@ __global__ void __launch_bounds__(256)
   }
   ushort4* pc = projColor + (size_t)tab * plane;
   ushort4* pb = projBias + (size_t)tab * plane;
+  // the random-proposal kernel's copy of projColor in 4x4-texel tiles (null when the context does not keep one)
+  const int tilesX = tiled_tiles_x(V.W);
+  ushort4* pt = projColorT ? projColorT + (size_t)tab * tiled_plane(V.W, V.H) : nullptr;
   const int lx = threadIdx.x & 31;
   const int x = x0 + lx;
   if (x >= V.W) {
@@ -1125,6 +1350,9 @@ __global__ void __launch_bounds__(256)
       for (int ox = oxa; ox <= oxb; ++ox) {
         pc[(size_t)oy * OW + ox] = col;
         pb[(size_t)oy * OW + ox] = bia;
+        if (pt) {
+          pt[tiled_index(tilesX, ox, oy)] = col;
+        }
       }
     }
   }
@@ -1308,7 +1536,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
 #else
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
 #endif
-  unsigned nCost = 0, nPair = 0;
+  unsigned nCost = 0, nPair = 0, nSlots = 0, nSlotsFirst = 0;
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
     const int own = V.dst2src[d];
     const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
@@ -1322,7 +1550,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
         const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float currDisp = disp[idx];
         unsigned before = nPair;
-        float2 cur = compute_cost<DERP_RANDOM_SSD_SCALAR != 0>(V, dl, own, px, currDisp, pairs, nPair, cull);
+        float2 cur = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true>(V, dl, own, px, currDisp, pairs, nPair, cull, 0, &nSlotsFirst);
         ++nCost;
         unsigned currPairs = nPair - before;
         float currCost = cur.x, currConf = cur.y;
@@ -1335,7 +1563,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
           const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
           const float propDisp = minstd_uniform(state, lo, hi);
           before = nPair;
-          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0>(V, dl, own, px, propDisp, pairs, nPair, cull);
+          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true>(V, dl, own, px, propDisp, pairs, nPair, cull, 0, &nSlots);
           ++nCost;
           if (pr.x < currCost && pr.x < costThresh) {
             currCost = pr.x;
@@ -1353,6 +1581,10 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
     }
   }
   flush_counters(V, nCost, nPair);
+#ifdef DERP_COUNT_UNION
+  atomicAdd(&V.counters[3], (unsigned long long)nSlots);       // random candidates: lane-slots the waves walked
+  atomicAdd(&V.counters[2], (unsigned long long)nSlotsFirst);  // the current disparity's evaluation
+#endif
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1379,9 +1611,15 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   unsigned nCost = 0, nPair = 0, nMemo = 0;
   if (x < V.W && y < V.H) {
     const int own = V.dst2src[d];
-    const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+    // per-destination planes (wave-uniform bases) and a 32-bit pixel index: the loads take the scalar-base + 32-bit
+    // offset form, and nothing 64-bit per lane has to survive the candidate loop
+    const size_t n = (size_t)V.W * V.H;
+    const unsigned idx = (unsigned)y * (unsigned)V.W + (unsigned)x;
     const float* disp = V.disparity + (size_t)d * n;
     const uint8_t* fov = V.fovMask + (size_t)d * n;
+    const uint8_t* chg = changed + (size_t)d * n;
+    dispRes += (size_t)d * n;
+    costRes += (size_t)d * n;
     float outDisp = disp[idx];
     float outCost = __builtin_inff();
     const bool interior = x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1;
@@ -1390,7 +1628,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
         outDisp = V.bgDisp[(size_t)d * n + idx];
       } else if (!(V.srcVar[(size_t)own * n + idx] < V.varNoiseFloor)) {
         PixCtx px;
-        load_pixctx(V, d, own, x, y, px);
+        load_pixctx<!DERP_PP_RELOAD_RAY>(V, d, own, x, y, px);
         const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float bestCost = __builtin_inff();
         float bestDisp = outDisp;
@@ -1398,20 +1636,24 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
         for (int k = 0; k < 9; ++k) {
           const int xx = min(max(x + kCandidates[k][0], 0), V.W - 1);
           const int yy = min(max(y + kCandidates[k][1], 0), V.H - 1);
-          const size_t j = (size_t)yy * V.W + xx;
+          const unsigned j = (unsigned)yy * (unsigned)V.W + (unsigned)xx;
           if (fov[j]) {
             const float cand = disp[j];
-            if (cand >= bg && changed[(size_t)d * n + j]) {
+            if (cand >= bg && chg[j]) {
               float2 r;
               // Candidate (0,0) is the pixel's own disparity. In the first iteration, where random
               // proposals evaluated this pixel, computeCost(own disparity) is exactly the value they
               // left in cost / confidence (a pure function of the same arguments): reuse it.
-              if (k == 0 && useMemo && V.confidence[(size_t)d * n + idx] != 0.0f) {
-                r = make_float2(V.cost[(size_t)d * n + idx], V.confidence[(size_t)d * n + idx]);
-                nPair += V.pairCount[(size_t)d * n + idx];
+              // (the opaque copy of the index keeps these three addresses out of the registers the loop carries)
+              unsigned mi = idx;
+              asm volatile("" : "+v"(mi));
+              const float memoConf = (k == 0 && useMemo) ? (V.confidence + (size_t)d * n)[mi] : 0.0f;
+              if (memoConf != 0.0f) {
+                r = make_float2((V.cost + (size_t)d * n)[mi], memoConf);
+                nPair += (V.pairCount + (size_t)d * n)[mi];
                 ++nMemo;
               } else {
-                r = compute_cost<DERP_COST_SSD_SCALAR != 0>(V, dl, own, px, cand, pairs, nPair, cull);
+                r = compute_cost<DERP_COST_SSD_SCALAR != 0, false, DERP_PP_RELOAD_RAY != 0>(V, dl, own, px, cand, pairs, nPair, cull, idx);
               }
               ++nCost;
               if (r.x < bestCost) {
@@ -1425,8 +1667,8 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
         outCost = bestCost;
       }
     }
-    dispRes[(size_t)d * n + idx] = outDisp;
-    costRes[(size_t)d * n + idx] = outCost;
+    dispRes[idx] = outDisp;
+    costRes[idx] = outCost;
   }
   flush_counters(V, nCost, nPair);
   for (int off = 32; off > 0; off >>= 1) {

@@ -75,3 +75,17 @@ def test_restated_libstdcxx_algorithms(built):
     # jump-ahead far into the stream
     ref = O.minstd_uniform(99, 100001, 0.0, 1.0)
     assert ref[100000] == np.float32(derp.host_minstd_uniform(99, 100000, 0.0, 1.0))
+
+
+def test_block_bias_rounding_identity():
+    """k_random_proposals sums the 3x3 colour-bias boxes from the 4x4 texel block in fp32 and rounds with
+    trunc((s + 4) * fl(1/9)) (derp_kernels.h, DERP_RANDOM_BLOCK_BIAS); k_reproject_bias, like cv::blur on CV_16UC3
+    (DerpUtil.cpp:208-210), rounds the integer sum with (s + 4) / 9. The two agree for EVERY possible sum of nine
+    16-bit texels, and every such sum (+ 4) is exact in fp32."""
+    import numpy as np
+
+    s = np.arange(0, 9 * 65535 + 1, dtype=np.int64)
+    f = s.astype(np.float32)
+    assert np.array_equal(f.astype(np.int64), s) and np.array_equal((f + np.float32(4)).astype(np.int64), s + 4)
+    q = np.trunc((f + np.float32(4)) * np.float32(1.0 / 9.0))
+    assert q.dtype == np.float32 and np.array_equal(q.astype(np.int64), (s + 4) // 9)

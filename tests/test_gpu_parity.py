@@ -423,8 +423,8 @@ def test_destination_subset(small):
 
 def test_destination_batching(small, monkeypatch):
     """Config 4's memory path: when the projection tables of all destinations do not fit the table
-    budget, destinations are processed in batches (DERP_TABLE_BUDGET_GB caps the budget; 7 MB here
-    leaves room for two of the six). Results and counters must not depend on the batch size."""
+    budget, destinations are processed in batches (DERP_TABLE_BUDGET_GB caps the budget; 12 MB here
+    leaves room for two of the six, 6 MB for one). Results and counters must not depend on the batch size."""
     from facebook360_dep_amd import derp
 
     def run():
@@ -439,7 +439,7 @@ def test_destination_batching(small, monkeypatch):
         return out, c
 
     whole, c_whole = run()
-    for budget in ("0.007", "0.004"):
+    for budget in ("0.012", "0.006"):
         monkeypatch.setenv("DERP_TABLE_BUDGET_GB", budget)
         batched, c_batched = run()
         assert c_batched == c_whole
