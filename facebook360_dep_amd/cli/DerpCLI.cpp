@@ -33,9 +33,14 @@ int main(int argc, char** argv) {
   F.parse(argc, argv);
   Timer total;
   DerpJob J(F);
-  J.setup();
+  J.setup_host();
+  const double tHost = total.s();
+  J.setup_device(-1);
+  const double tDevice = total.s();
   J.create_output_dirs();
   derp_ctx* ctx = J.ctx;
+  LOG_INFO(fmt("-- start-up: flags + rig + input check %.3fs, HIP runtime + context %.3fs, output dirs %.3fs", tHost,
+               tDevice - tHost, total.s() - tDevice));
 
   IoPool pool(F.i("threads"));
   FrameStager stager(J, pool);

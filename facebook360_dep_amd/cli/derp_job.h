@@ -54,6 +54,9 @@ struct DerpJob {
   std::vector<int> W, H;
   int widthFull = 0, heightFull = 0;
   derp_ctx* ctx = nullptr;
+  // TemporalBilateralFilter on the sequence engine: ONE level whose raw disparities come from disk (dispLevels =
+  // --disparity) instead of being computed; no background disparities, no previous level
+  bool filterOnly = false;
 
   explicit DerpJob(Flags& f) : F(f) {}
   static fs::path levelDir(const fs::path& base, int level) { return base / ("level_" + std::to_string(level)); }
@@ -91,7 +94,7 @@ struct DerpJob {
     CHECK_MSG(fs::is_directory(F.s("color")), "No images in " + F.s("color"));
     useFg = F.b("use_foreground_masks");
     if (useFg) {
-      CHECK_MSG(fs::is_directory(F.s("background_disp")),
+      CHECK_MSG(filterOnly || fs::is_directory(F.s("background_disp")),
                 "Asked to use background but no background disparities found in " + F.s("background_disp"));
       CHECK_MSG(fs::is_directory(F.s("foreground_masks")),
                 "Asked to use foreground masks but no foreground masks found in " + F.s("foreground_masks"));
@@ -113,10 +116,14 @@ struct DerpJob {
     CHECK_MSG(!rigSrc.empty(), "no source cameras!");
     rigDst = filter_destinations(rigSrc, F.s("cameras"));
     CHECK_MSG(!rigDst.empty(), "no destination cameras!");
+    if (filterOnly) {
+      rigSrc = rigDst;  // the filter reads each destination's own colour (and mask) only
+    }
     S = (int)rigSrc.size();
     D = (int)rigDst.size();
     // ---- pyramid geometry (DerpCLI.cpp:194-215)
-    dispLevels = fs::path(outputRoot) / "disparity_levels";
+    dispLevels = filterOnly && F.defs.count("disparity") && !F.s("disparity").empty() ? fs::path(F.s("disparity"))
+                                                                                : fs::path(outputRoot) / "disparity_levels";
     pyramid_level_sizes(sizes, F.s("color"));
     pyramid_level_sizes(sizes, dispLevels);
     CHECK_MSG(!sizes.empty(), "No pyramid levels found in " + F.s("color"));
@@ -141,11 +148,15 @@ struct DerpJob {
     // verifyInputImagePaths (DerpCLI.cpp:137-156)
     verify_image_paths(levelDir(F.s("color"), levelStart), rigSrc, F.s("first"), F.s("last"));
     if (useFg) {
-      verify_image_paths(levelDir(F.s("background_disp"), levelStart), rigDst, F.s("background_frame"),
-                         F.s("background_frame"));
+      if (!filterOnly) {
+        verify_image_paths(levelDir(F.s("background_disp"), levelStart), rigDst, F.s("background_frame"),
+                           F.s("background_frame"));
+      }
       verify_image_paths(levelDir(F.s("foreground_masks"), levelStart), rigDst, F.s("first"), F.s("last"));
     }
-    if (levelStart < numLevels - 1) {
+    if (filterOnly) {
+      verify_image_paths(levelDir(dispLevels, levelStart), rigDst, F.s("first"), F.s("last"));
+    } else if (levelStart < numLevels - 1) {
       verify_image_paths(levelDir(dispLevels, levelStart + 1), rigDst, F.s("first"), F.s("last"));
     }
     fs::create_directories(outputRoot);
@@ -154,7 +165,7 @@ struct DerpJob {
     // levels outside [levelEnd, min(levelStart + 1, numLevels - 1)] are declared absent (no HBM spent on them)
     W.assign(numLevels, 0);
     H.assign(numLevels, 0);
-    const int topLevel = std::min(levelStart + 1, numLevels - 1);
+    const int topLevel = filterOnly ? levelStart : std::min(levelStart + 1, numLevels - 1);
     for (int l = levelEnd; l <= topLevel; ++l) {
       CHECK_MSG(sizes.count(l), fmt("no images found for level %d", l));
       W[l] = sizes[l].first;
@@ -423,7 +434,7 @@ struct FrameStore {
   bool throttle = true;
 
   FrameStore(const DerpJob& job, IoPool& p, const std::vector<int>& owned) : J(job), pool(p), frames(owned) {
-    inTop = J.levelStart < J.numLevels - 1 ? J.levelStart + 1 : J.levelStart;
+    inTop = J.levelStart < J.numLevels - 1 && !J.filterOnly ? J.levelStart + 1 : J.levelStart;
     data.resize(frames.size());
     for (auto& f : data) {
       f.resize(J.numLevels);
@@ -439,6 +450,9 @@ struct FrameStore {
   size_t level_bytes(int level) const {
     const size_t n = J.npx(level);
     const bool compute = level <= J.levelStart;
+    if (J.filterOnly) {
+      return n * 6 * J.S + (J.useFg ? n * J.S : 0) + n * 4 * J.D;
+    }
     return (compute ? n * 6 * J.S : 0) + (J.useFg ? n * J.S + (compute ? n * 4 * J.D : 0) : 0) + (compute ? 0 : n * 4 * J.D);
   }
   void schedule(int k, int level) { pending.emplace_back(k, level); }
@@ -481,7 +495,7 @@ struct FrameStore {
     }
     if (J.useFg) {
       L.mask.resize(n * J.S);
-      if (compute) {
+      if (compute && !J.filterOnly) {
         L.bg.resize(n * J.D);
       }
     }
@@ -502,7 +516,7 @@ struct FrameStore {
         });
       }
     }
-    if (J.useFg && compute) {
+    if (J.useFg && compute && !J.filterOnly) {
       for (int d = 0; d < J.D; ++d) {
         float* dst = L.bg.data() + n * d;
         const fs::path path = image_path(DerpJob::levelDir(F.s("background_disp"), level), J.rigDst[d].id,
@@ -515,11 +529,13 @@ struct FrameStore {
         });
       }
     }
-    if (!compute) {  // resume: previous level from disk (DerpCLI.cpp:287-288)
+    if (!compute || J.filterOnly) {  // resume: previous level from disk (DerpCLI.cpp:287-288); or the level to filter
       L.prev.resize(n * J.D);
       for (int d = 0; d < J.D; ++d) {
         float* dst = L.prev.data() + n * d;
-        const fs::path path = image_path(DerpJob::levelDir(J.dispLevels, level), J.rigDst[d].id, frameName, ".pfm");
+        // (the filter's input may be whatever cv::imread reads, first extension of the directory: ImageUtil.h:48-56)
+        const fs::path path = J.filterOnly ? image_path(DerpJob::levelDir(J.dispLevels, level), J.rigDst[d].id, frameName)
+                                           : image_path(DerpJob::levelDir(J.dispLevels, level), J.rigDst[d].id, frameName, ".pfm");
         B.add(pool, [=] {
           int pw, ph;
           const std::vector<float> prev = load_float(path, pw, ph);
@@ -598,8 +614,34 @@ struct FrameStore {
                                         L.mask.empty() ? nullptr : L.mask.data(), L.bg.empty() ? nullptr : L.bg.data()));
     }
     if (!L.prev.empty()) {
-      for (int d = 0; d < J.D; ++d) {
-        DERP_OK(ctx, derp_seq_upload_disparity(seq, frames[k], level, d, L.prev.data() + J.npx(level) * d));
+      const size_t dn = J.npx(level);
+      if (ring && J.filterOnly) {
+        // the level to filter is as large as the colour: through the same page-locked planes (a float plane fits a
+        // colour plane's 6 bytes per pixel), pool workers copying plane d + 1.. while plane d moves at the PCIe rate
+        const bool inlineCopy = dn * sizeof(float) < (4u << 20);
+        auto stage = [&](int d) {
+          void* dst = bounce[d % kBounce].p;
+          const float* src = L.prev.data() + dn * d;
+          if (inlineCopy) {
+            memcpy(dst, src, dn * sizeof(float));
+          } else {
+            bounceReady[d % kBounce].add(pool, [=] { memcpy(dst, src, dn * sizeof(float)); }, 0);
+          }
+        };
+        for (int d = 0; d < std::min(kBounce, J.D); ++d) {
+          stage(d);
+        }
+        for (int d = 0; d < J.D; ++d) {
+          bounceReady[d % kBounce].wait();
+          DERP_OK(ctx, derp_seq_upload_disparity(seq, frames[k], level, d, static_cast<const float*>(bounce[d % kBounce].p)));
+          if (d + kBounce < J.D) {
+            stage(d + kBounce);
+          }
+        }
+      } else {
+        for (int d = 0; d < J.D; ++d) {
+          DERP_OK(ctx, derp_seq_upload_disparity(seq, frames[k], level, d, L.prev.data() + dn * d));
+        }
       }
     }
     if (resident) {  // every byte is in HBM (the calls above return after their copies): give the host memory back

@@ -97,6 +97,9 @@ namespace derp {
 #ifndef DERP_PP_RELOAD_RAY
 #define DERP_PP_RELOAD_RAY 1
 #endif
+#ifndef DERP_RANDOM_RELOAD_RAY
+#define DERP_RANDOM_RELOAD_RAY 0
+#endif
 #ifndef DERP_RANDOM_RECONVERT
 #define DERP_RANDOM_RECONVERT 1
 #endif
@@ -372,6 +375,41 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     const float xf = roundf(xDstSrc), yf = roundf(yDstSrc);
     const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
     const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
+    if constexpr (!SCALAR) {
+      // packed form: (B, G) of a texel as one register pair; R of the two tap columns as one pair
+      v2f topBG[2], botBG[2], topR, botR;  // [tap column] / (tap column 0, tap column 1)
+#pragma unroll
+      for (int r = 3; r >= 0; --r) {
+        const u4a8 a = raw[r][0], b = raw[r][1];
+        const v2f m = bg_of(a.z) + bg_of(b.x);
+        v2f hA = m + bg_of(a.x), hB = m + bg_of(b.z);
+        const float mR = (float)(a.w & 0xffff) + (float)(b.y & 0xffff);
+        v2f hR = splat2(mR) + (v2f){(float)(a.y & 0xffff), (float)(b.w & 0xffff)};
+        if (r == 3 || r == 2) {  // first row of a box: start it at + 4 (round(s / 9) = (s + 4) / 9)
+          const v2f four = splat2(4.0f);
+          if (r == 3) {
+            botBG[0] = hA + four, botBG[1] = hB + four, botR = hR + four;
+          } else {
+            botBG[0] += hA, botBG[1] += hB, botR += hR;
+            topBG[0] = hA + four, topBG[1] = hB + four, topR = hR + four;
+          }
+        } else if (r == 1) {
+          botBG[0] += hA, botBG[1] += hB, botR += hR;
+          topBG[0] += hA, topBG[1] += hB, topR += hR;
+        } else {
+          topBG[0] += hA, topBG[1] += hB, topR += hR;
+        }
+      }
+      const v2f ninth = splat2(1.0f / 9.0f);
+      const v2f t00 = trunc2(topBG[0] * ninth), t01 = trunc2(topBG[1] * ninth), t10 = trunc2(botBG[0] * ninth),
+                t11 = trunc2(botBG[1] * ninth);
+      const v2f tR = trunc2(topR * ninth), bR = trunc2(botR * ninth);
+      const v2f sbBG = trunc2(splat2(w00) * t00 + splat2(w01) * t01 + splat2(w10) * t10 + splat2(w11) * t11);
+      const v2f bBG = px.dstBiasBG - sbBG;
+      bias[0] = bBG.x;
+      bias[1] = bBG.y;
+      bias[2] = px.dstBiasR - bilerp_u16(tR.x, tR.y, bR.x, bR.y, w00, w01, w10, w11);
+    } else {
     float top[3][2], bot[3][2];  // [channel][tap column]: rows 0..2 and rows 1..3
 #pragma unroll
     for (int r = 3; r >= 0; --r) {
@@ -409,6 +447,7 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
       const float t00 = __builtin_truncf(top[ch][0] * ninth), t01 = __builtin_truncf(top[ch][1] * ninth);
       const float t10 = __builtin_truncf(bot[ch][0] * ninth), t11 = __builtin_truncf(bot[ch][1] * ninth);
       bias[ch] = px.dstBias(ch) - bilerp_u16(t00, t01, t10, t11, w00, w01, w10, w11);
+    }
     }
     if (__ballot(border) != 0ull) {  // taps on the image's rim: the table's values (loaded by ssd_issue_random)
       if (border) {
@@ -524,10 +563,27 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     const float omxm = 1 - xwm;
     float d0s[3][3], d1s[3][3];  // [ix][iy]
     RowF lo, hi;
+    auto again = [](const u4a8& v) {  // see block_scalar
+      u4a8 o = v;
+      if constexpr (BLOCK_BIAS && DERP_RANDOM_RECONVERT) {
+        unsigned a = v.x, b = v.y, c = v.z, d = v.w;
+        asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        o = (u4a8){a, b, c, d};
+      }
+      return o;
+    };
     unpack(raw[0][0], raw[0][1], lo);
 #pragma unroll
     for (int iy = 0; iy < 3; ++iy) {
-      unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+      if constexpr (BLOCK_BIAS) {
+        if (iy >= 1) {
+          unpack(again(raw[iy + 1][0]), again(raw[iy + 1][1]), hi);
+        } else {
+          unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+        }
+      } else {
+        unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
+      }
       const float omy = 1 - yw[iy];
       // weights of the offsets dx = -1 / +1 as pairs, of dx = 0 as scalars
       const v2f w00p = omxp * splat2(omy), w01p = xwp * splat2(omy), w10p = omxp * splat2(yw[iy]),
@@ -1546,11 +1602,11 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
         disp[idx] = V.bgDisp[(size_t)d * n + idx];
       } else if (random_gate(V, d, own, idx)) {
         PixCtx px;
-        load_pixctx(V, d, own, x, y, px);
+        load_pixctx<!DERP_RANDOM_RELOAD_RAY>(V, d, own, x, y, px);
         const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float currDisp = disp[idx];
         unsigned before = nPair;
-        float2 cur = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true>(V, dl, own, px, currDisp, pairs, nPair, cull, 0, &nSlotsFirst);
+        float2 cur = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, currDisp, pairs, nPair, cull, (unsigned)idx, &nSlotsFirst);
         ++nCost;
         unsigned currPairs = nPair - before;
         float currCost = cur.x, currConf = cur.y;
@@ -1563,7 +1619,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
           const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
           const float propDisp = minstd_uniform(state, lo, hi);
           before = nPair;
-          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true>(V, dl, own, px, propDisp, pairs, nPair, cull, 0, &nSlots);
+          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, propDisp, pairs, nPair, cull, (unsigned)idx, &nSlots);
           ++nCost;
           if (pr.x < currCost && pr.x < costThresh) {
             currCost = pr.x;

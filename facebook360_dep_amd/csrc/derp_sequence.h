@@ -1143,6 +1143,40 @@ int derp_seq_level_compute_frame(derp_seq* q, int level, int frame) {
   return 0;
 }
 
+// An owned frame's raw level that was computed elsewhere and uploaded (derp_seq_upload_disparity): counts as this
+// frame's compute of the level. It is what TemporalBilateralFilter's inputs are — DerpCLI's files of the level, read
+// back from disk (TemporalBilateralFilter.cpp:139-160) — so that the executable can run on the sequence driver's
+// resident frames and per-frame filter instead of re-reading every window frame for every frame it filters.
+int derp_seq_level_provided_frame(derp_seq* q, int level, int frame) {
+  if (!q) {
+    return 1;
+  }
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  const int k = owned_index(q, frame);
+  if (k < 0) {
+    return fail(c, "frame %d is not owned by rank %d", frame, q->rank);
+  }
+  if (q->streaming) {
+    return fail(c, "derp_seq_level_provided_frame needs the frames resident in HBM");
+  }
+  TRY(select_frame(c, k));
+  if (!c->haveDisp[level]) {
+    return fail(c, "frame %d has no level %d disparity (derp_seq_upload_disparity of every destination first)", frame, level);
+  }
+  if (q->computeLevel != level) {
+    q->computeLevel = level;
+    q->computedFrames = 0;
+    q->levelReady = -1;
+  }
+  q->computedAt[k] = level;
+  q->filteredAt[k] = -1;
+  if (++q->computedFrames >= (int)q->owned.size()) {
+    q->levelReady = level;
+  }
+  return 0;
+}
+
 int derp_seq_level_compute(derp_seq* q, int level) {
   if (!q) {
     return 1;

@@ -69,7 +69,7 @@ EXPORTS = [
     "derp_seq_attach_rccl", "derp_seq_attach_loopback", "derp_seq_attach_external", "derp_seq_selftest",
     "derp_seq_exchange_inputs", "derp_seq_level_compute", "derp_seq_level_exchange", "derp_seq_level_filter",
     "derp_seq_host_inputs", "derp_seq_buffer_copy", "derp_seq_upload_color_plane", "derp_seq_upload_disparity", "derp_seq_download_disparity", "derp_seq_exchange_inputs_level",
-    "derp_seq_level_compute_frame", "derp_seq_mark_exchanged", "derp_seq_level_filter_frame", "derp_seq_download_filtered",
+    "derp_seq_level_compute_frame", "derp_seq_level_provided_frame", "derp_seq_mark_exchanged", "derp_seq_level_filter_frame", "derp_seq_download_filtered",
     "derp_seq_run", "derp_seq_stats", "derp_seq_stats_reset",
 ]
 

@@ -341,6 +341,9 @@ int derp_seq_exchange_inputs(derp_seq* seq);               /* colour (+ fg) pyra
 int derp_seq_exchange_inputs_level(derp_seq* seq, int level);  /* ... one level of them (inputs that arrive level by level) */
 int derp_seq_level_compute(derp_seq* seq, int level);      /* processLevel(level) of every owned frame */
 int derp_seq_level_compute_frame(derp_seq* seq, int level, int frame);  /* ... of one owned frame (each once per level) */
+/* ... or: the frame's raw level was computed by another process and uploaded with derp_seq_upload_disparity
+ * (TemporalBilateralFilter's inputs: DerpCLI's files of the level, TemporalBilateralFilter.cpp:139-160) */
+int derp_seq_level_provided_frame(derp_seq* seq, int level, int frame);
 int derp_seq_level_exchange(derp_seq* seq, int level);     /* raw level disparity of the halo frames */
 int derp_seq_mark_exchanged(derp_seq* seq, int level);     /* external transport: the halo frames' level has arrived */
 int derp_seq_level_filter(derp_seq* seq, int level);       /* temporal filter of every owned frame + Transfer; fails

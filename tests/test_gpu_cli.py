@@ -219,6 +219,51 @@ def test_temporal_cli(dataset, tmp_path):
             assert bad == 0, (cur, cam, bad, rel)
 
 
+def test_temporal_cli_engine_equals_frame_by_frame(dataset, tmp_path):
+    """TemporalBilateralFilter runs a level on the sequence driver (every frame of the chunk decoded and uploaded once, a
+    frame filtered as soon as its window is in HBM) whenever the windows are those of a contiguous run of frames, and
+    falls back to the reference's frame-by-frame loop (filterFrame, TemporalBilateralFilter.cpp:121-184) otherwise:
+    the two write the same bytes — plain, a sub-range of the frames on disk (windows reach past --first / --last), with
+    foreground masks, a --cameras subset, PNG output — and a gap in the frame numbering takes the fallback."""
+    import shutil
+
+    root = dataset["root"]
+    rigf = os.path.join(root, "rigs", "rig_calibrated.json")
+    ids = [c["id"] for c in dataset["rig"]["cameras"]]
+    raw = str(tmp_path / "raw")
+    run("DerpCLI", "--input_root=" + root, "--output_root=" + raw, "--first=000000", "--last=000002", "--partial_coverage",
+        "--resolution=96", "--level_end=1")
+    cases = [("all", ["--first=000000", "--last=000002"]),
+             ("middle", ["--first=000001", "--last=000001", "--time_radius=1"]),
+             ("masks", ["--first=000000", "--last=000002", "--use_foreground_masks", "--output_formats=pfm,png"]),
+             ("subset", ["--first=000000", "--last=000001", "--cameras=%s,%s" % (ids[2], ids[0]), "--space_radius=2", "--sigma=0.02"])]
+    for name, extra in cases:
+        outs = {}
+        for mode in ("engine", "legacy"):
+            out = str(tmp_path / (name + "_" + mode))
+            shutil.copytree(os.path.join(raw, "disparity_levels"), os.path.join(out, "disparity_levels"))
+            env = dict(os.environ, DERP_TBF_LEGACY="1") if mode == "legacy" else None
+            p = run("TemporalBilateralFilter", "--input_root=" + root, "--output_root=" + out, "--rig=" + rigf, "--level=1",
+                    *extra, env=env)
+            assert ("read once each" in p.stderr) == (mode == "engine"), p.stderr[-2000:]
+            outs[mode] = os.path.join(out, "disparity_time_filtered_levels", "level_1")
+        cams = sorted(os.listdir(outs["legacy"]))
+        assert cams == sorted(os.listdir(outs["engine"])) and cams
+        for cam in cams:
+            files = sorted(os.listdir(os.path.join(outs["legacy"], cam)))
+            assert files == sorted(os.listdir(os.path.join(outs["engine"], cam))) and files, (name, cam)
+            for f in files:
+                assert open(os.path.join(outs["legacy"], cam, f), "rb").read() == \
+                    open(os.path.join(outs["engine"], cam, f), "rb").read(), (name, cam, f)
+    # a hole in the numbering (frame 1 of one input missing): windows are no longer those of one contiguous run
+    gap = str(tmp_path / "gap")
+    shutil.copytree(os.path.join(raw, "disparity_levels"), os.path.join(gap, "disparity_levels"))
+    os.remove(os.path.join(gap, "disparity_levels", "level_1", ids[0], "000001.pfm"))
+    p = run("TemporalBilateralFilter", "--input_root=" + root, "--output_root=" + gap, "--rig=" + rigf, "--level=1",
+            "--first=000000", "--last=000000", "--time_radius=2", expect_ok=False)
+    assert "read once each" not in p.stderr
+
+
 def test_derp_sequence_cli_equals_the_three_binary_pipeline(dataset, tmp_path):
     """The depth_estimation stage of scripts/render/pipeline.py:364-408 two ways: (a) the way the reference
     orchestrates it — per level, DerpCLI on every frame, TemporalBilateralFilter on every frame, then "Transfer"

@@ -1,0 +1,129 @@
+#!/usr/bin/env python
+"""Time the reference's own calling pattern with this build's drop-in binaries (VERDICT r4 "missing" #2).
+
+The caller of source/depth_estimation is scripts/render/pipeline.py:364-408 (workers: worker.py:66-107,180-266): for
+every pyramid level, coarse to fine, ONE `DerpCLI --level_start=L --level_end=L` per frame chunk, then ONE
+`TemporalBilateralFilter --level=L` per chunk, then "Transfer" (the filtered level copied over disparity_levels/level_L),
+with the file system between all of them: 2 x levels process launches per chunk, each paying process start, the HIP
+runtime, the level's rig-only tables and its inputs from disk. This script writes a BASELINE-config dataset, runs exactly
+that schedule (one chunk = all frames, one worker) and prints, per invocation, the wall time around the process and the
+binary's own split (start-up = flags + rig + HIP runtime and context; compute; I/O waits), then the same data set through
+bin/DerpSequence (one process, frames resident in HBM) and compares the two results byte for byte.
+
+usage: tools/pipeline_timing.py [config=cfg2] [frames=8] [extra env KEY=VALUE ...]   (on the GPU box)"""
+import filecmp
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from facebook360_dep_amd import synth  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+env = dict(os.environ)
+for kv in sys.argv[3:]:
+    k, v = kv.split("=", 1)
+    env[k] = v
+BIN = os.path.join(ROOT, "facebook360_dep_amd", "bin")
+n, res, widths = synth.config(cfg)
+rig = synth.make_rig(n, res)
+sizes = synth.level_sizes(res, res, widths)
+n_levels = len(sizes)
+root = os.environ.get("PIPELINE_DATASET") or tempfile.mkdtemp(prefix="derp_pipe_", dir="/tmp")
+if not os.path.exists(os.path.join(root, "rigs")):
+    t0 = time.time()
+    synth.write_dataset(root, rig, list(range(frames)), sizes)
+    print("dataset: %d frame(s) of %s written in %.1f s under %s" % (frames, cfg, time.time() - t0, root))
+rigf = os.path.join(root, "rigs", "rig_calibrated.json")
+first, last = "000000", "%06d" % (frames - 1)
+
+
+def run(binary, *flags):
+    t0 = time.time()
+    p = subprocess.run([os.path.join(BIN, binary)] + list(flags), capture_output=True, text=True, env=env)
+    wall = time.time() - t0
+    if p.returncode:
+        print(p.stderr[-3000:])
+        raise SystemExit("%s failed" % binary)
+    own = {}
+    for line in p.stderr.splitlines():
+        m = re.search(r"-- start-up: (.*)", line)
+        if m:
+            own["startup"] = m.group(1)
+            own["startup_s"] = sum(float(x) for x in re.findall(r"([0-9.]+)s", m.group(1).split("(")[0]))
+        m = re.search(r"-- TOTAL: ([0-9.]+)s", line)
+        if m:
+            own["total_s"] = float(m.group(1))
+        m = re.search(r"-- I/O vs compute.*compute ([0-9.]+)s", line)
+        if m:
+            own["compute_s"] = float(m.group(1))
+            own["io"] = line.split("-- I/O vs compute")[1].strip()
+        m = re.search(r"-- filter: (.*)", line)
+        if m:
+            own["io"] = m.group(1)
+            c = re.search(r"GPU ([0-9.]+)s", m.group(1))
+            if c:
+                own["compute_s"] = float(c.group(1))
+    return wall, own, p.stderr
+
+
+def schedule(out):
+    """pipeline.py:364-408 with one frame chunk and one worker."""
+    rows, t_all = [], time.time()
+    common_flags = ["--input_root=" + root, "--first=" + first, "--last=" + last, "--resolution=%d" % res] + \
+        (["--partial_coverage"] if n <= 4 else [])
+    for level in range(n_levels - 1, -1, -1):
+        w, own, _ = run("DerpCLI", *common_flags, "--output_root=" + out, "--level_start=%d" % level, "--level_end=%d" % level)
+        rows.append(("DerpCLI", level, w, own))
+        w, own, _ = run("TemporalBilateralFilter", "--input_root=" + root, "--output_root=" + out, "--rig=" + rigf,
+                        "--first=" + first, "--last=" + last, "--level=%d" % level)
+        rows.append(("TemporalBilateralFilter", level, w, own))
+        t0 = time.time()  # "Transfer": the filtered level replaces the raw one (setup.py / worker.py copy the files)
+        src = os.path.join(out, "disparity_time_filtered_levels", "level_%d" % level)
+        dst = os.path.join(out, "disparity_levels", "level_%d" % level)
+        shutil.rmtree(dst)
+        shutil.copytree(src, dst)
+        rows.append(("Transfer", level, time.time() - t0, {}))
+    return rows, time.time() - t_all
+
+
+out_a = os.path.join(root, "out_schedule")
+shutil.rmtree(out_a, ignore_errors=True)
+rows, wall_a = schedule(out_a)
+print("%-24s %5s %8s %9s %9s %9s   %s" % ("step", "level", "wall s", "start-up", "compute", "rest", "binary's own I/O line"))
+tot = {"wall": 0.0, "startup": 0.0, "compute": 0.0}
+for name, level, w, own in rows:
+    su, co = own.get("startup_s", 0.0), own.get("compute_s", 0.0)
+    tot["wall"] += w
+    tot["startup"] += su
+    tot["compute"] += co
+    print("%-24s %5d %8.3f %9.3f %9.3f %9.3f   %s" % (name, level, w, su, co, w - su - co, own.get("io", "")))
+launches = sum(1 for r in rows if r[0] != "Transfer")
+print("schedule: %d process launches + %d transfers: %.2f s wall (start-up %.2f s, GPU compute %.2f s, everything else "
+      "%.2f s) = %.1f Mpix/s disk to disk" % (launches, n_levels, wall_a, tot["startup"], tot["compute"],
+                                              wall_a - tot["startup"] - tot["compute"], frames * n * res * res / wall_a / 1e6))
+
+out_b = os.path.join(root, "out_sequence")
+shutil.rmtree(out_b, ignore_errors=True)
+wall_b, own, err = run("DerpSequence", "--input_root=" + root, "--output_root=" + out_b, "--first=" + first, "--last=" + last,
+                       "--resolution=%d" % res, *(["--partial_coverage"] if n <= 4 else []))
+print("DerpSequence: %.2f s wall (its TOTAL line %.2f s) = %.1f Mpix/s disk to disk; schedule / DerpSequence = %.2f" % (
+    wall_b, own.get("total_s", 0.0), frames * n * res * res / wall_b / 1e6, wall_a / wall_b))
+same = total = 0
+for kind in ("disparity_levels", "disparity_time_filtered_levels"):
+    for level in range(n_levels):
+        base = os.path.join(out_a, kind, "level_%d" % level)
+        for cam in sorted(os.listdir(base)):
+            for f in sorted(os.listdir(os.path.join(base, cam))):
+                total += 1
+                same += filecmp.cmp(os.path.join(base, cam, f), os.path.join(out_b, kind, "level_%d" % level, cam, f), shallow=False)
+print("outputs: %d of %d files byte-identical between the schedule and DerpSequence" % (same, total))
+if not os.environ.get("PIPELINE_DATASET"):
+    shutil.rmtree(root, ignore_errors=True)
