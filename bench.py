@@ -113,7 +113,16 @@ def cpu_baseline(rig, sizes, frame, res, n_cams, mode="auto"):
 
     threads = os.cpu_count() or 1
     cores = usable_cpus()
-    out = {"unit": "Mpix/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    out = {"unit": "Mpix/s", "cores": cores, "kind": "port", "cpu_model": model,
            "threads": threads,
            "cores_note": "%d worker threads (one per visible hardware thread) on %d usable CPUs (scheduler affinity and "
                          "cgroup CPU quota of this container)" % (threads, cores)}
@@ -361,69 +370,57 @@ def main():
         stale = ("profiles/valu_roofline.json was collected on kernel sources %s..., this tree is %s...: counter-derived "
                  "fields withheld" % (str(prof.get("kernel_sources_sha256"))[:12], here[:12]))
         prof = {}
-    n_cost_launch = pp["n_cost"] / launches
-    n_pair_launch = pp["n_pair"] / launches
-    # executed = logical minus the evaluations served from the memo (their pairs are not executed either)
-    exec_frac = 1.0 - memo / n_cost_launch if n_cost_launch else 1.0
-    alg_bytes_exec = b_alg(n_cost_launch, n_pair_launch) * exec_frac
-    kernel_s = kernel_ms * 1e-3
-    # VALU issue cycles of one level-0 launch: rocprofv3's typed instruction counters priced per instruction class at
-    # the issue intervals tools/valu_ubench.hip measured on this chip (tools/valu_model.py; round 3 charged every
-    # instruction 4 cycles / summed a per-wave busy counter, which read above 1 for some kernels)
-    issue_cycles = prof.get("ping_pong_level0_issue_cycles_per_launch")
-    issue_low = prof.get("ping_pong_level0_issue_cycles_if_simple_ops_coissue")
-    achieved = issue_cycles / kernel_s / 1e9 if issue_cycles and kernel_s > 0 else None
-    traffic = prof.get("ping_pong_level0_hbm_bytes_per_launch")
-    # the arithmetic the reference's algorithm needs for the executed (call, source) pairs, at the same class costs
-    alg_valu = None
-    cc = prof.get("ping_pong_level0_class_cycles")
-    if cc and kernel_s > 0:
-        per_pair = 372.0 * cc["S"] + 90.0 * cc["F"] + 84.0 * cc["D"] + 3.0 * cc["T64"]  # tools/valu_model.py ALG_PER_PAIR
-        alg_valu = {"cycles_per_pair": round(per_pair, 1),
-                    "frac": round(n_pair_launch * exec_frac * per_pair / 64.0 / kernel_s / 1e9 / VALU_PEAK_GCYC, 4),
-                    "note": "operations computeSSD + Camera::sees need per executed (cost call, source) pair (372 plain fp32, "
-                            "90 conversions / truncations, 84 fp64, 3 fp64 transcendental; tools/valu_model.py) x pairs / 64 "
-                            "lanes, priced like the executed instructions: what an instruction-perfect kernel would issue"}
-    roofline = {
-        "kernel": "k_ping_pong @ level 0",
-        "bound": "valu",
-        "achieved": round(achieved, 1) if achieved else None,
-        "peak": VALU_PEAK_GCYC,
-        "unit": "G SIMD issue-cycles/s",
-        "frac": round(achieved / VALU_PEAK_GCYC, 4) if achieved else None,
-        "traffic": traffic,
-        "kernel_ms": round(kernel_ms, 3),
-        "launches_timed": pp["launches"],
-        "note": ("achieved = sum over instruction classes of (instructions of one level-0 launch, rocprofv3 typed VALU "
-                 "counters) x (issue cycles per wave64 instruction of that class, measured by tools/valu_ubench.hip at the "
-                 "kernel's waves per SIMD: plain fp32 add/mul, moves, logic 2.1-2.8; other 32-bit 4.2; fp64 and packed "
-                 "fp32 4.4; fp64 rcp/rsq/sqrt 16) / this run's HIP-event launch duration; peak = %d SIMDs x %.1f GHz. "
-                 "The kernel gathers from L1/L2-resident tables: HBM is not its bound (hbm_frac below), VALU issue is."
-                 % (N_SIMD, PEAK_CLOCK_GHZ)),
-        "stale": stale,
-        # plain fp32 / move / logic instructions can issue beside a 4-cycle instruction of another wave (two 16-lane
-        # halves per SIMD): if every one of them found such a slot the pipe time would be this much
-        "frac_if_simple_ops_coissue": (round(issue_low / kernel_s / 1e9 / VALU_PEAK_GCYC, 4)
-                                       if issue_low and kernel_s > 0 else None),
-        "algorithmic_valu": alg_valu,
-        # NOT a roofline (round 3's figure): VALU-active quad-cycles summed over the resident waves / chip cycles
-        "occupancy_valu_busy_NOT_A_BOUND": prof.get("ping_pong_level0_valu_busy_frac"),
-        "waves_per_simd": prof.get("ping_pong_level0_waves_per_simd"),
-        "wave_issue_breakdown": prof.get("ping_pong_level0_wave_cycle_shares"),
-        "hbm_traffic_GBps": round(traffic / kernel_s / 1e9, 1) if traffic and kernel_s > 0 else None,
-        "hbm_frac": round(traffic / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if traffic and kernel_s > 0 else None,
-        "algorithmic": {  # SURVEY 8(d)'s logical gather bytes: secondary, on EXECUTED evaluations only
-            "bytes_per_launch_executed": alg_bytes_exec,
-            "GBps": round(alg_bytes_exec / kernel_s / 1e9, 1) if kernel_s > 0 else None,
-            "logical_rate_over_hbm_peak_NOT_A_BOUND": round(alg_bytes_exec / kernel_s / 1e9 / HBM_PEAK_GBS, 4) if kernel_s > 0 else None,
-            "note": "SURVEY 8(d)'s B_alg: logical gathers (64 B / cost call + 272 B / (call, source) pair); neighbouring "
-                    "pixels share texels and L1/L2 serve them, so this ratio exceeds 1 and bounds nothing. The HBM "
-                    "fraction 8(d) asks for is hbm_frac above: measured traffic of the launch / 8 TB/s",
-            "n_cost_per_launch": n_cost_launch, "n_pair_per_launch": n_pair_launch,
-            "memoised_cost_evals_per_launch": memo,
-        },
-        "whole_step_algorithmic_GBps": round(b_alg(cnt["n_cost"], cnt["n_pair"]) / dt / 1e9, 1),
-    }
+    def kernel_roofline(name, stage, key, memo_evals):
+        """SURVEY 8(d) for one cost kernel's level-0 launch. `frac` is ACHIEVEMENT: the VALU issue cycles the reference's
+        own arithmetic needs for the (cost call, source) pairs the launch executed / the cycles the chip had during the
+        launch. `issue_frac` is ACTIVITY: the instruction stream the kernel really issued, priced the same way (low =
+        every plain fp32 / move / logic instruction co-issues beside a 4-cycle instruction of another wave, high = none
+        does). `hbm_frac` = bytes through the memory-side counters / launch time / 8 TB/s."""
+        q = g.profile_query(stage, 0)
+        n_l = max(q["launches"], 1)
+        ms = q["ms"] / n_l
+        sec = ms * 1e-3
+        n_cost_l, n_pair_l = q["n_cost"] / n_l, q["n_pair"] / n_l
+        exec_frac = 1.0 - memo_evals / n_cost_l if n_cost_l else 1.0  # evaluations served from the memo execute no pairs
+        cc = prof.get(key + "_level0_class_cycles")
+        hi, lo = prof.get(key + "_level0_issue_cycles_per_launch"), prof.get(key + "_level0_issue_cycles_if_simple_ops_coissue")
+        traffic = prof.get(key + "_level0_hbm_bytes_per_launch")
+        out = {"kernel": "%s @ level 0" % name, "bound": "valu", "unit": "G SIMD issue-cycles/s", "peak": VALU_PEAK_GCYC,
+               "achieved": None, "frac": None, "traffic": traffic, "kernel_ms": round(ms, 3), "launches_timed": q["launches"]}
+        if cc and sec > 0:
+            per_pair = 372.0 * cc["S"] + 90.0 * cc["F"] + 84.0 * cc["D"] + 3.0 * cc["T64"]  # tools/valu_model.py ALG_PER_PAIR
+            ach = n_pair_l * exec_frac * per_pair / 64.0 / sec / 1e9
+            out["achieved"] = round(ach, 1)
+            out["frac"] = round(ach / VALU_PEAK_GCYC, 4)
+            out["algorithmic_cycles_per_pair"] = round(per_pair, 1)
+            out["class_cycles"] = {k: round(v, 3) for k, v in cc.items() if isinstance(v, float)}
+            out["waves_per_simd"] = prof.get(key + "_level0_waves_per_simd")
+        if hi and lo and sec > 0:
+            out["issue_frac"] = {"low": round(lo / sec / 1e9 / VALU_PEAK_GCYC, 4), "high": round(hi / sec / 1e9 / VALU_PEAK_GCYC, 4)}
+        if traffic and sec > 0:
+            out["hbm_traffic_GBps"] = round(traffic / sec / 1e9, 1)
+            out["hbm_frac"] = round(traffic / sec / 1e9 / HBM_PEAK_GBS, 4)
+        if prof.get(key + "_level0_l2"):
+            out["l2"] = prof[key + "_level0_l2"]
+        out["wave_issue_breakdown"] = prof.get(key + "_level0_wave_cycle_shares")
+        alg_bytes = b_alg(n_cost_l, n_pair_l) * exec_frac
+        out["logical_gathers"] = {  # SURVEY 8(d)'s B_alg on executed evaluations: L1 / L2 serve most of it, so this is no bound
+            "bytes_per_launch_executed": alg_bytes, "n_cost_per_launch": n_cost_l, "n_pair_per_launch": n_pair_l,
+            "memoised_cost_evals_per_launch": memo_evals,
+            "rate_over_hbm_peak_NOT_A_BOUND": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 4) if sec > 0 else None}
+        return out
+
+    roofline = kernel_roofline("k_ping_pong", "ping_pong", "ping_pong", memo)
+    roofline["note"] = (
+        "frac = (executed (cost call, source) pairs of one level-0 launch) x (VALU issue cycles the reference's arithmetic "
+        "needs per pair: 372 plain fp32, 90 conversions / truncations, 84 fp64, 3 fp64 transcendental — tools/valu_model.py "
+        "ALG_PER_PAIR — priced per class at the intervals tools/valu_ubench.hip measured on this chip, at the kernel's "
+        "measured waves per SIMD) / 64 lanes / this run's HIP-event launch time / (%d SIMDs x %.1f GHz). issue_frac prices the "
+        "instructions the kernel really issued (rocprofv3 typed VALU counters) the same way: [all simple ops co-issue, none "
+        "does]. The kernel gathers from L1 / L2-resident tables: HBM is not its bound (hbm_frac)." % (N_SIMD, PEAK_CLOCK_GHZ))
+    roofline["stale"] = stale
+    roofline["random_proposals"] = kernel_roofline("k_random_proposals", "random_proposals", "random", 0.0)
+    roofline["whole_step_algorithmic_GBps"] = round(b_alg(cnt["n_cost"], cnt["n_pair"]) / dt / 1e9, 1)
     # SURVEY 8(d): measured HBM bytes of a whole step (all kernels; the committed PMC passes ran the default
     # sequence on one GPU, so only quoted for that shape) beside the compulsory floor: every source level read
     # once per destination + disparity / masks read and written once

@@ -177,6 +177,21 @@ for n, view in entry["kernels_level0_launch"].items():
     im = issue_model(n, view)
     if im:
         view["issue_model"] = im
+for short, kname in (("random", "k_random_proposals"),):  # the same fields for the second cost kernel of the step
+    v = entry["kernels_level0_launch"][kname]
+    im = v.get("issue_model")
+    entry[short + "_level0_hbm_bytes_per_launch"] = v.get("hbm_bytes_per_launch")
+    entry[short + "_level0_waves_per_simd"] = v.get("waves_per_simd_avg")
+    entry[short + "_level0_wave_cycle_shares"] = v.get("wave_cycle_shares")
+    if im:
+        entry[short + "_level0_issue_cycles_per_launch"] = im["issue_cycles_per_launch"]
+        entry[short + "_level0_issue_cycles_if_simple_ops_coissue"] = im["issue_cycles_if_simple_ops_coissue"]
+        entry[short + "_level0_class_cycles"] = im["class_cycles_used"]
+    l2 = pm.get("L2", {})
+    for k, x in l2.items():
+        if kname in k and "TCC_REQ_sum" in x:
+            req, miss = x["TCC_REQ_sum"]["max"], x.get("TCC_MISS_sum", {}).get("max", 0.0)
+            entry[short + "_level0_l2"] = {"requests": req, "misses": miss, "hit_rate": round(1.0 - miss / max(req, 1.0), 4)}
 ppm = entry["kernels_level0_launch"]["k_ping_pong("].get("issue_model")
 if ppm:
     entry["ping_pong_level0_issue_cycles_per_launch"] = ppm["issue_cycles_per_launch"]

@@ -76,9 +76,7 @@ def counter_of(op):
     return "OTHER"
 
 
-def class_costs(ubench_path, waves):
-    """-> {class: cycles per wave64 instruction on one SIMD} at `waves` resident waves per SIMD (1..4, clamped)."""
-    w = int(min(max(round(waves), 1), 4))
+def _column(ubench_path, w):
     rows = [json.loads(ln) for ln in open(ubench_path) if ln.startswith("{")]
     t = {}
     for r in rows:
@@ -88,8 +86,22 @@ def class_costs(ubench_path, waves):
     return {"S": pick(["add_f32", "mul_f32", "mov_b32", "and_b32", "add_u32"]),
             "F": pick(["fma_f32", "cvt_f32_u32_sdwa", "trunc_f32", "cmp_lt_f32", "max_f32", "mul_lo_u32"]),
             "D": pick(["add_f64", "mul_f64", "fma_f64", "pk_mul_f32", "pk_add_f32", "lshlrev_b64"]),
-            "T32": pick(["rcp_f32", "sqrt_f32", "exp_f32"]), "T64": pick(["rcp_f64", "rsq_f64", "sqrt_f64"]),
-            "waves_column": w}
+            "T32": pick(["rcp_f32", "sqrt_f32", "exp_f32"]), "T64": pick(["rcp_f64", "rsq_f64", "sqrt_f64"])}
+
+
+def class_costs(ubench_path, waves):
+    """-> {class: cycles per wave64 instruction on one SIMD} at the kernel's MEASURED average of `waves` resident waves
+    per SIMD: the two neighbouring columns of the micro-benchmark (1..4 waves) mixed in the proportion that gives that
+    average — 2.91 waves = 91 % of the time three waves (plain fp32 2.80 cycles), 9 % two (2.08). Round 4 took the
+    rounded column, i.e. the worst one for a three-wave kernel."""
+    w = min(max(float(waves), 1.0), 4.0)
+    lo = int(w) if w < 4 else 3
+    f = w - lo
+    a, b = _column(ubench_path, lo), _column(ubench_path, lo + 1)
+    out = {k: (1 - f) * a[k] + f * b[k] for k in a}
+    out["waves_per_simd"] = round(w, 3)
+    out["waves_columns_mixed"] = [lo, lo + 1, round(1 - f, 3), round(f, 3)]
+    return out
 
 
 _asm = {}
