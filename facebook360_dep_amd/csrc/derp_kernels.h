@@ -782,8 +782,12 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
   const double depth = (double)(1.0f / disparity);
   D3 rayD = px.rayD;
   if constexpr (RELOAD_RAY) {
+    // NOT volatile: clang gives a volatile asm no memory(none) attribute, MemorySSA then takes it for a store, and every
+    // uniform load behind it (the source cameras' constants, once per projection) leaves the scalar cache for per-lane
+    // vector loads — measured: +11 % on this kernel. A pure asm would be hoisted out of the candidate loop with the
+    // loads it is meant to pin there; tying it to the candidate's disparity keeps it loop-variant.
     unsigned i = pix;
-    asm volatile("" : "+v"(i));
+    asm("" : "+v"(i) : "v"(disparity));
     const double* rd = V.rayDir + (size_t)(V.dst0 + dl) * ((size_t)V.W * V.H);
     rayD = {rd[i], rd[V.rayStride + i], rd[2 * V.rayStride + i]};
   }
@@ -1702,7 +1706,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
               // left in cost / confidence (a pure function of the same arguments): reuse it.
               // (the opaque copy of the index keeps these three addresses out of the registers the loop carries)
               unsigned mi = idx;
-              asm volatile("" : "+v"(mi));
+              asm("" : "+v"(mi) : "v"(cand));  // (not volatile, tied to the candidate: see compute_cost)
               const float memoConf = (k == 0 && useMemo) ? (V.confidence + (size_t)d * n)[mi] : 0.0f;
               if (memoConf != 0.0f) {
                 r = make_float2((V.cost + (size_t)d * n)[mi], memoConf);
