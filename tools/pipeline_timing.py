@@ -32,6 +32,7 @@ for kv in sys.argv[3:]:
     k, v = kv.split("=", 1)
     env[k] = v
 BIN = os.path.join(ROOT, "facebook360_dep_amd", "bin")
+THREADS = os.environ.get("PIPELINE_THREADS")  # --threads of every binary (default: the binaries' own -1 = auto)
 n, res, widths = synth.config(cfg)
 rig = synth.make_rig(n, res)
 sizes = synth.level_sizes(res, res, widths)
@@ -41,13 +42,15 @@ if not os.path.exists(os.path.join(root, "rigs")):
     t0 = time.time()
     synth.write_dataset(root, rig, list(range(frames)), sizes)
     print("dataset: %d frame(s) of %s written in %.1f s under %s" % (frames, cfg, time.time() - t0, root))
+print("DATASET_ROOT=" + root)
 rigf = os.path.join(root, "rigs", "rig_calibrated.json")
 first, last = "000000", "%06d" % (frames - 1)
 
 
 def run(binary, *flags):
     t0 = time.time()
-    p = subprocess.run([os.path.join(BIN, binary)] + list(flags), capture_output=True, text=True, env=env)
+    p = subprocess.run([os.path.join(BIN, binary)] + list(flags) + (["--threads=" + THREADS] if THREADS else []),
+                       capture_output=True, text=True, env=env)
     wall = time.time() - t0
     if p.returncode:
         print(p.stderr[-3000:])
@@ -125,5 +128,5 @@ for kind in ("disparity_levels", "disparity_time_filtered_levels"):
                 total += 1
                 same += filecmp.cmp(os.path.join(base, cam, f), os.path.join(out_b, kind, "level_%d" % level, cam, f), shallow=False)
 print("outputs: %d of %d files byte-identical between the schedule and DerpSequence" % (same, total))
-if not os.environ.get("PIPELINE_DATASET"):
+if not os.environ.get("PIPELINE_DATASET") and not os.environ.get("PIPELINE_KEEP"):
     shutil.rmtree(root, ignore_errors=True)
