@@ -101,6 +101,16 @@ static bool run_on_sequence_engine(Flags& F, const std::vector<derp_camera_desc>
   DerpJob J(G);
   J.filterOnly = true;
   J.setup_host();
+  {
+    // every frame of A..B stays in HBM for the level (colour 8 B, raw + filtered disparity 8 B, masks 2 B per pixel and
+    // camera): a chunk that would not fit comfortably takes the frame-by-frame path, which holds one window at a time
+    const double bytes = (double)(B - A + 1) * J.D * (double)J.npx(level) * 20.0;
+    const char* e = getenv("DERP_TBF_HBM_BUDGET_GB");
+    if (bytes > (e ? atof(e) : 128.0) * 1e9) {
+      LOG_INFO(fmt("frames %06d..%06d of level %d need %.1f GB resident: filtering frame by frame instead", A, B, level, bytes / 1e9));
+      return false;
+    }
+  }
   std::vector<int> owned;
   for (int f = A; f <= B; ++f) {
     owned.push_back(f);

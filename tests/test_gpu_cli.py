@@ -255,6 +255,17 @@ def test_temporal_cli_engine_equals_frame_by_frame(dataset, tmp_path):
             for f in files:
                 assert open(os.path.join(outs["legacy"], cam, f), "rb").read() == \
                     open(os.path.join(outs["engine"], cam, f), "rb").read(), (name, cam, f)
+    # a chunk too large to keep resident (budget forced to nothing here) takes the frame-by-frame path as well
+    big = str(tmp_path / "big")
+    shutil.copytree(os.path.join(raw, "disparity_levels"), os.path.join(big, "disparity_levels"))
+    p = run("TemporalBilateralFilter", "--input_root=" + root, "--output_root=" + big, "--rig=" + rigf, "--level=1",
+            "--first=000000", "--last=000002", env=dict(os.environ, DERP_TBF_HBM_BUDGET_GB="0.000001"))
+    assert "read once each" not in p.stderr and "frame by frame instead" in p.stderr
+    ref_dir = os.path.join(str(tmp_path / "all_legacy"), "disparity_time_filtered_levels", "level_1")
+    for cam in sorted(os.listdir(ref_dir)):
+        for f in sorted(os.listdir(os.path.join(ref_dir, cam))):
+            assert open(os.path.join(ref_dir, cam, f), "rb").read() == \
+                open(os.path.join(big, "disparity_time_filtered_levels", "level_1", cam, f), "rb").read(), (cam, f)
     # a hole in the numbering (frame 1 of one input missing): windows are no longer those of one contiguous run
     gap = str(tmp_path / "gap")
     shutil.copytree(os.path.join(raw, "disparity_levels"), os.path.join(gap, "disparity_levels"))
