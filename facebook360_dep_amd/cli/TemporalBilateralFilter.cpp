@@ -212,7 +212,7 @@ int main(int argc, char** argv) {
   F.str("rig", "", "path to camera rig .json (required)");
   F.dbl("sigma", 0.01, "spatio-temporal smoothing");
   F.i32("space_radius", -1, "space filtering radius");
-  F.i32("threads", -1, "number of threads (-1 = auto, 0 = none) [accepted; the GPU path ignores it]");
+  F.i32("threads", -1, "number of threads (-1 = auto, 0 = none) [here: image decode / file write workers; the filter is the GPU's]");
   F.i32("time_radius", 2, "temporal filtering radius");
   F.boolean("use_foreground_masks", false, "use pre-computed foreground masks");
   F.dbl("weight_b", 0.5, "Blue channel weight");
