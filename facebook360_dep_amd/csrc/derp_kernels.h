@@ -97,6 +97,14 @@ namespace derp {
 #ifndef DERP_PP_RELOAD_RAY
 #define DERP_PP_RELOAD_RAY 1
 #endif
+// a wave whose lanes are all in computeSSD's exact case runs a copy of the 4x4-block arithmetic specialised for it
+#ifndef DERP_UNIFORM_WEIGHTS
+#define DERP_UNIFORM_WEIGHTS 1
+#endif
+// ... also of the plain-fp32 form (random proposals): + 7 VGPRs there, i.e. the third wave unless they are found elsewhere
+#ifndef DERP_UNIFORM_WEIGHTS_SCALAR
+#define DERP_UNIFORM_WEIGHTS_SCALAR 0
+#endif
 #ifndef DERP_RANDOM_RELOAD_RAY
 #define DERP_RANDOM_RELOAD_RAY 0
 #endif
@@ -665,7 +673,18 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     }
     regular = (xi[0] == xi[1] - 1) && (xi[2] == xi[1] + 1) && (yi[0] == yi[1] - 1) && (yi[2] == yi[1] + 1);
   }
-  if (regular) {
+  if (DERP_UNIFORM_WEIGHTS && (!SCALAR || DERP_UNIFORM_WEIGHTS_SCALAR) && __ballot(!exact) == 0ull) {
+    // every lane of the wave is in the exact case (all but ~1 % of the waves: x or y inside [2^k - 1, 2^k) or below 1
+    // breaks it): ONE weight per axis serves the nine offsets, and this copy of the block says so at compile time —
+    // the weight products are formed once instead of once per offset row, and no values of the general path have to
+    // be merged in (three dozen register moves per call in the shared copy)
+    const float ywu[3] = {yw[1], yw[1], yw[1]};
+    if constexpr (SCALAR) {
+      block_scalar(splat2(xw[1]), xw[1], ywu);
+    } else {
+      block_packed(splat2(xw[1]), xw[1], ywu);
+    }
+  } else if (regular) {
     if constexpr (SCALAR) {
       block_scalar((v2f){xw[0], xw[2]}, xw[1], yw);
     } else {
