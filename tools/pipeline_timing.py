@@ -83,11 +83,15 @@ def schedule(out):
     common_flags = ["--input_root=" + root, "--first=" + first, "--last=" + last, "--resolution=%d" % res] + \
         (["--partial_coverage"] if n <= 4 else [])
     for level in range(n_levels - 1, -1, -1):
-        w, own, _ = run("DerpCLI", *common_flags, "--output_root=" + out, "--level_start=%d" % level, "--level_end=%d" % level)
+        w, own, err = run("DerpCLI", *common_flags, "--output_root=" + out, "--level_start=%d" % level, "--level_end=%d" % level)
         rows.append(("DerpCLI", level, w, own))
+        if os.environ.get("PIPELINE_DUMP") and level == 0:
+            print("---- DerpCLI level 0 stderr (wall %.3f s)\n" % w + err + "----")
         w, own, _ = run("TemporalBilateralFilter", "--input_root=" + root, "--output_root=" + out, "--rig=" + rigf,
                         "--first=" + first, "--last=" + last, "--level=%d" % level)
         rows.append(("TemporalBilateralFilter", level, w, own))
+        if os.environ.get("PIPELINE_DUMP") and level == 0:
+            print("---- TemporalBilateralFilter level 0 stderr (wall %.3f s)\n" % w + _ + "----")
         t0 = time.time()  # "Transfer": the filtered level replaces the raw one (setup.py / worker.py copy the files)
         src = os.path.join(out, "disparity_time_filtered_levels", "level_%d" % level)
         dst = os.path.join(out, "disparity_levels", "level_%d" % level)
