@@ -210,7 +210,11 @@ DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = n
     const double xy = sqrt(p.x * p.x + p.y * p.y);
     double r;
     if (-p.z <= 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      r = sk(tan(M_PI / 2));  // (a scalar: left alone the folded literal rides in a vector register pair through every kernel)
+#else
       r = tan(M_PI / 2);
+#endif
     } else {
       r = xy / -p.z;
     }

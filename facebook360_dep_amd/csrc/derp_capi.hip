@@ -144,11 +144,11 @@ struct derp_ctx {
 
   bool profiling = false;
   bool noMemo = false;  // DERP_NO_MEMO (developer switch), read once in derp_create
-  // waves per SIMD of the random-proposal / ping-pong kernels (0 = what their registers allow, three): a launch can ask
-  // for fewer by reserving more LDS per (one-wave) block — the kernels that miss L2 trade latency hiding against the
-  // working set their resident waves spread over it, and the right answer depends on the level size (DERP_RANDOM_WAVES,
-  // DERP_PP_WAVES: developer A/B; randomWavesBigLevel: the policy, see run_random_proposals)
+  // waves per SIMD of the random-proposal / ping-pong kernels (0 = what their registers and LDS allow: four up to 16
+  // cameras): a launch can ask for fewer by reserving more LDS per (one-wave) block — DERP_RANDOM_WAVES / DERP_PP_WAVES,
+  // developer A/B switches
   int randomWaves = 0, ppWaves = 0;
+  size_t ldsPerCu = 160 * 1024;  // hipDeviceProp.maxSharedMemoryPerMultiProcessor (derp_create)
   bool noTemporalTile = false;  // DERP_NO_TEMPORAL_TILE (developer A/B: the direct form of the temporal filter)
   bool noBlankSkip = false;     // DERP_NO_BLANK_SKIP (developer A/B: every frame rewrites the blank tiles of the colour tables)
   std::vector<TimedSpan> spans;
@@ -239,6 +239,8 @@ LevelView make_view(derp_ctx* c, int stage, int dst0, int nd) {
   const int L = c->cur;
   V.W = c->LW[L];
   V.H = c->LH[L];
+  V.Wd = (double)V.W;
+  V.Hd = (double)V.H;
   V.S = c->S;
   V.D = nd;
   V.level = L;
@@ -609,13 +611,16 @@ constexpr size_t kCostLdsPerSrc = (size_t)DERP_COST_BLOCK * sizeof(SsdPair);
 int round8(int n) {
   return (n + 7) / 8 * 8;
 }
-// dynamic LDS of a one-wave block such that at most `waves` blocks per SIMD (4 x waves per CU) fit a CU's 160 KB
-size_t lds_for_waves(size_t needed, int waves) {
-  if (waves <= 0 || waves >= 3) {
+// dynamic LDS of a one-wave block such that at most `waves` blocks per SIMD (4 x waves per CU) fit a CU's LDS
+// (`ldsPerCu`: hipDeviceProp.maxSharedMemoryPerMultiProcessor, 160 KB on gfx950); `fixed` = the kernel's static LDS
+size_t lds_for_waves(size_t needed, int waves, size_t ldsPerCu, size_t fixed) {
+  if (waves <= 0 || waves >= 4) {
     return needed;
   }
-  return std::max(needed, (size_t)(160 * 1024 / (4 * waves + 1) + 256));
+  const size_t perBlock = ldsPerCu / (size_t)(4 * waves + 1) + 256;  // 4 * waves blocks fit, 4 * waves + 1 do not
+  return std::max(needed, perBlock > fixed ? perBlock - fixed : needed);
 }
+constexpr size_t kCostLdsStatic = sizeof(PatchWin) * (DERP_COST_BLOCK / 64) + kAtanLutDoubles * sizeof(double);
 
 int run_brute_force(derp_ctx* c, int dst0, int nd) {
   const int L = c->cur;
@@ -656,7 +661,7 @@ int run_random_proposals(derp_ctx* c, int dst0, int nd) {
   }
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->randomWaves);
+  const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->randomWaves, c->ldsPerCu, kCostLdsStatic);
   hipLaunchKernelGGL(k_random_proposals, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->rank.as<int>(),
                      tilesX, tiles);
   KCHECK(c);
@@ -674,7 +679,7 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   HIPCHK(c, hipMemsetAsync(c->changed.as<uint8_t>() + (size_t)dst0 * n, 1, n * nd, c->stream));
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
-  const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->ppWaves);
+  const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->ppWaves, c->ldsPerCu, kCostLdsStatic);
   for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
     hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->changed.as<uint8_t>(),
                        c->dispRes.as<float>(), c->costRes.as<float>(), tilesX,
@@ -1109,6 +1114,9 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
     return bail("hipSetDevice failed");
   }
   c->device = device;
+  if (prop.maxSharedMemoryPerMultiProcessor > 0) {
+    c->ldsPerCu = prop.maxSharedMemoryPerMultiProcessor;
+  }
   if (const char* e = getenv("DERP_XCD_ROTATE")) {
     c->xcdRotate = atoi(e);
   }

@@ -26,14 +26,17 @@
 
 namespace derp {
 
-// waves per SIMD the register allocator must leave room for (__launch_bounds__): the cost kernels with coherent
-// gathers (ping-pong, brute force, cost map) run three (<= 168 VGPRs), random proposals two — its gathers miss L2
-// and a third wave only widens the working set (measured: 48.8 / 51.7 / 55.3 ms per frame at 2 / 3 / 4 waves)
+// waves per SIMD the register allocator must leave room for (__launch_bounds__). Round 6: FOUR for every cost kernel
+// (<= 128 VGPRs) — the destination patch lives in LDS (PatchWin), the 4x4 block is streamed by columns (no parked sums),
+// and the candidate loops carry a handful of values. Rounds 2-5 ran three (164-167 VGPRs), an odd count at which a plain
+// fp32 op costs 2.8 instead of 2.08 cycles (tools/valu_ubench.hip). Measured on one box (profiles/r06_kernel_variants.txt):
+// level-0 ping-pong 59.8 -> 55.0 ms, random proposals 42.3 -> 39.9 ms per frame; the same sources held to three waves:
+// 61.8 / 42.0. What still spills at 128 is cold: a few per-pixel / per-candidate values around the source loops.
 #ifndef DERP_COST_MIN_WAVES
-#define DERP_COST_MIN_WAVES 3
+#define DERP_COST_MIN_WAVES 4
 #endif
 #ifndef DERP_RANDOM_MIN_WAVES
-#define DERP_RANDOM_MIN_WAVES 2
+#define DERP_RANDOM_MIN_WAVES 4
 #endif
 #ifndef DERP_COST_BLOCK
 #define DERP_COST_BLOCK 64
@@ -105,8 +108,9 @@ namespace derp {
 #ifndef DERP_UNIFORM_WEIGHTS_SCALAR
 #define DERP_UNIFORM_WEIGHTS_SCALAR 0
 #endif
+// random proposals: the same (round 6: six registers the fourth wave needs)
 #ifndef DERP_RANDOM_RELOAD_RAY
-#define DERP_RANDOM_RELOAD_RAY 0
+#define DERP_RANDOM_RELOAD_RAY 1
 #endif
 #ifndef DERP_RANDOM_RECONVERT
 #define DERP_RANDOM_RECONVERT 1
@@ -127,6 +131,7 @@ typedef unsigned int u4a8 __attribute__((ext_vector_type(4), aligned(8)));
 
 struct LevelView {
   int W, H, S, D;             // D = dst cameras in this batch
+  double Wd, Hd;              // (double)W, (double)H: kernel arguments, i.e. scalar registers in the cost kernels' projection
   int level, numLevels;
   int dst0;                   // first dst of the batch (global dst index = dst0 + dl)
   int hasFg;
@@ -237,24 +242,52 @@ __device__ __forceinline__ v2f bg_of(unsigned u) {
   return (v2f){(float)(u & 0xffff), (float)(u >> 16)};
 }
 
+// The destination colours a wave's 8x8 pixel tile compares against — the 3x3 patches of its 64 pixels overlap, so the
+// wave keeps ONE 10x10 window of its destination camera's colour (as floats) in LDS instead of 27 floats per lane in
+// registers (round 6: those 27 + the 18 parked per-offset sums were what pinned the cost kernels at 164-167 VGPRs, an odd
+// three waves per SIMD). (B, G) and R live in separate planes: a (B, G) pair arrives as one aligned register pair
+// (ds_read_b64), and R of the offsets dy = -1 / +1 as one pair too (ds_read2_b32, two rows of the R plane).
+static constexpr int kWinW = 10, kWinTexels = kWinW * kWinW;
+struct PatchWin {
+  v2f bg[kWinTexels];
+  float r[kWinTexels];
+};
+
 struct PixCtx {
   D3 rayO, rayD;        // dst ray (Camera::rig(pixel) of the dst pixel centre)
-  // dst colour 3x3, index (dx+1)*3 + (dy+1) — computeSSD's loop order — laid out for packed fp32:
-  // (B, G) of every offset as one register pair; R of the offsets dx = -1 / +1 paired per dy
-  v2f patchBG[9];
-  v2f patchR02[3];
-  float patchR1[3];
+  // dst colour 3x3: offset (dx, dy) = (ix - 1, iy - 1) is texel [iy * kWinW + ix] from the lane's corner of the window
+  const v2f* winBG;
+  const float* winR;
   v2f dstBiasBG;
   float dstBiasR;
-  __device__ __forceinline__ float patch(int o, int c) const {
-    const int ix = o / 3, iy = o - 3 * ix;
-    return c == 0 ? patchBG[o].x : c == 1 ? patchBG[o].y : ix == 1 ? patchR1[iy] : ix == 0 ? patchR02[iy].x : patchR02[iy].y;
+  __device__ __forceinline__ v2f patchBG(int ix, int iy) const {
+    return winBG[iy * kWinW + ix];
+  }
+  __device__ __forceinline__ float patchR(int ix, int iy) const {
+    return winR[iy * kWinW + ix];
+  }
+  __device__ __forceinline__ float patch(int ix, int iy, int c) const {
+    return c == 2 ? patchR(ix, iy) : c == 0 ? patchBG(ix, iy).x : patchBG(ix, iy).y;
   }
   __device__ __forceinline__ float dstBias(int c) const {
     return c == 0 ? dstBiasBG.x : c == 1 ? dstBiasBG.y : dstBiasR;
   }
   float confidence;     // max(variance, kMinVar)
 };
+
+// Fill the wave's window: texel (i, j) = pixel (x0 - 1 + i, y0 - 1 + j) of camera `own`, clamped to the image (a clamped
+// texel is only ever part of the patch of a border pixel, and those never reach computeCost). Every lane of the wave
+// takes part; the caller's barrier (one wave per block: a wait on the LDS queue) publishes it.
+__device__ __forceinline__ void patch_window_fill(const LevelView& V, int own, int x0, int y0, PatchWin* win) {
+  const ushort4* col = V.srcColor + (size_t)own * ((size_t)V.W * V.H);
+  for (int t = (int)(threadIdx.x & 63); t < kWinTexels; t += 64) {
+    const int j = t / kWinW, i = t - j * kWinW;
+    const int xx = min(max(x0 - 1 + i, 0), V.W - 1), yy = min(max(y0 - 1 + j, 0), V.H - 1);
+    const ushort4 q = col[(size_t)yy * V.W + xx];
+    win->bg[t] = (v2f){(float)q.x, (float)q.y};
+    win->r[t] = (float)q.z;
+  }
+}
 
 // selection scratch in LDS: pairs[i][thread]
 struct LdsPairs {
@@ -373,79 +406,82 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
 #endif
   const int pitch = V.W + 2 * kPadC;
   const u4a8 (&raw)[4][2] = T.raw;
+  // texel (row r, column k) of the 4x4 block: the (B | G << 16) word and the R word
+  auto word_bg = [&](const u4a8 (&q)[4][2], int r, int k) { return (k & 1) ? q[r][k >> 1].z : q[r][k >> 1].x; };
+  auto word_r = [&](const u4a8 (&q)[4][2], int r, int k) { return (k & 1) ? q[r][k >> 1].w : q[r][k >> 1].y; };
   // --- srcBias = getPixelBilinear(dstSrcColorBias, xDstSrc, yDstSrc)
   float bias[3];
   if constexpr (BLOCK_BIAS) {
     // The four taps are 3x3 boxes of projColor (colorBias, DerpUtil.cpp:208-210: cv::blur on CV_16UC3 = exact integer sum,
-    // round(s / 9)) over block columns 0..2 / 1..3 and rows 0..2 / 1..3. Rows are visited 3, 2, 1, 0 so that the floats
-    // of rows 1 and 0 are the ones the block arithmetic below starts with; rows 2 and 3 are converted again there
-    // (their words pass through an empty asm below: kept live instead, the 48 floats cost the kernel its third wave).
+    // round(s / 9)) over block columns 0..2 / 1..3 and rows 0..2 / 1..3. Columns are visited 3, 2, 1, 0 so that the floats
+    // of columns 1 and 0 are the ones the block arithmetic below starts with; columns 2 and 3 are converted again there
+    // (their words pass through an empty asm below: kept live instead, the 24 floats cost the kernel a wave).
     const float xf = roundf(xDstSrc), yf = roundf(yDstSrc);
     const float xw = xDstSrc - xf + 0.5f, yw = yDstSrc - yf + 0.5f;
     const float w00 = (1 - xw) * (1 - yw), w01 = xw * (1 - yw), w10 = (1 - xw) * yw, w11 = xw * yw;
     if constexpr (!SCALAR) {
-      // packed form: (B, G) of a texel as one register pair; R of the two tap columns as one pair
-      v2f topBG[2], botBG[2], topR, botR;  // [tap column] / (tap column 0, tap column 1)
+      // packed form: (B, G) of a texel as one register pair; R of (rows 0..2, rows 1..3) as one pair
+      v2f topBG[2], botBG[2], tbR[2];  // [tap column]
 #pragma unroll
-      for (int r = 3; r >= 0; --r) {
-        const u4a8 a = raw[r][0], b = raw[r][1];
-        const v2f m = bg_of(a.z) + bg_of(b.x);
-        v2f hA = m + bg_of(a.x), hB = m + bg_of(b.z);
-        const float mR = (float)(a.w & 0xffff) + (float)(b.y & 0xffff);
-        v2f hR = splat2(mR) + (v2f){(float)(a.y & 0xffff), (float)(b.w & 0xffff)};
-        if (r == 3 || r == 2) {  // first row of a box: start it at + 4 (round(s / 9) = (s + 4) / 9)
-          const v2f four = splat2(4.0f);
-          if (r == 3) {
-            botBG[0] = hA + four, botBG[1] = hB + four, botR = hR + four;
-          } else {
-            botBG[0] += hA, botBG[1] += hB, botR += hR;
-            topBG[0] = hA + four, topBG[1] = hB + four, topR = hR + four;
-          }
-        } else if (r == 1) {
-          botBG[0] += hA, botBG[1] += hB, botR += hR;
-          topBG[0] += hA, topBG[1] += hB, topR += hR;
+      for (int k = 3; k >= 0; --k) {
+        const v2f m = bg_of(word_bg(raw, 1, k)) + bg_of(word_bg(raw, 2, k));
+        const v2f vT = m + bg_of(word_bg(raw, 0, k)), vB = m + bg_of(word_bg(raw, 3, k));
+        const float mR = (float)(word_r(raw, 1, k) & 0xffff) + (float)(word_r(raw, 2, k) & 0xffff);
+        const v2f vR = splat2(mR) + (v2f){(float)(word_r(raw, 0, k) & 0xffff), (float)(word_r(raw, 3, k) & 0xffff)};
+        const v2f four = splat2(4.0f);  // first column of a box: start it at + 4 (round(s / 9) = (s + 4) / 9)
+        if (k == 3) {
+          topBG[1] = vT + four, botBG[1] = vB + four, tbR[1] = vR + four;
+        } else if (k == 2) {
+          topBG[1] += vT, botBG[1] += vB, tbR[1] += vR;
+          topBG[0] = vT + four, botBG[0] = vB + four, tbR[0] = vR + four;
+        } else if (k == 1) {
+          topBG[1] += vT, botBG[1] += vB, tbR[1] += vR;
+          topBG[0] += vT, botBG[0] += vB, tbR[0] += vR;
         } else {
-          topBG[0] += hA, topBG[1] += hB, topR += hR;
+          topBG[0] += vT, botBG[0] += vB, tbR[0] += vR;
         }
       }
       const v2f ninth = splat2(1.0f / 9.0f);
       const v2f t00 = trunc2(topBG[0] * ninth), t01 = trunc2(topBG[1] * ninth), t10 = trunc2(botBG[0] * ninth),
                 t11 = trunc2(botBG[1] * ninth);
-      const v2f tR = trunc2(topR * ninth), bR = trunc2(botR * ninth);
+      const v2f r0 = trunc2(tbR[0] * ninth), r1 = trunc2(tbR[1] * ninth);  // (top, bottom) of tap column 0 / 1
       const v2f sbBG = trunc2(splat2(w00) * t00 + splat2(w01) * t01 + splat2(w10) * t10 + splat2(w11) * t11);
       const v2f bBG = px.dstBiasBG - sbBG;
       bias[0] = bBG.x;
       bias[1] = bBG.y;
-      bias[2] = px.dstBiasR - bilerp_u16(tR.x, tR.y, bR.x, bR.y, w00, w01, w10, w11);
+      bias[2] = px.dstBiasR - bilerp_u16(r0.x, r1.x, r0.y, r1.y, w00, w01, w10, w11);
     } else {
     float top[3][2], bot[3][2];  // [channel][tap column]: rows 0..2 and rows 1..3
 #pragma unroll
-    for (int r = 3; r >= 0; --r) {
-      const u4a8 a = raw[r][0], b = raw[r][1];
-      const float c[3][4] = {
-          {(float)(a.x & 0xffff), (float)(a.z & 0xffff), (float)(b.x & 0xffff), (float)(b.z & 0xffff)},
-          {(float)(a.x >> 16), (float)(a.z >> 16), (float)(b.x >> 16), (float)(b.z >> 16)},
-          {(float)(a.y & 0xffff), (float)(a.w & 0xffff), (float)(b.y & 0xffff), (float)(b.w & 0xffff)}};
+    for (int k = 3; k >= 0; --k) {
+      float c[3][4];  // [channel][row] of block column k
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned bg = word_bg(raw, r, k), rr = word_r(raw, r, k);
+        c[0][r] = (float)(bg & 0xffff);
+        c[1][r] = (float)(bg >> 16);
+        c[2][r] = (float)(rr & 0xffff);
+      }
 #pragma unroll
       for (int ch = 0; ch < 3; ++ch) {
         const float m = c[ch][1] + c[ch][2];
-        const float hA = m + c[ch][0], hB = m + c[ch][3];
-        if (r == 3) {
-          bot[ch][0] = hA + 4.0f;  // the + 4 of round(s / 9) = (s + 4) / 9, once per tap
-          bot[ch][1] = hB + 4.0f;
-        } else if (r == 2) {
-          bot[ch][0] += hA;
-          bot[ch][1] += hB;
-          top[ch][0] = hA + 4.0f;
-          top[ch][1] = hB + 4.0f;
-        } else if (r == 1) {
-          bot[ch][0] += hA;
-          bot[ch][1] += hB;
-          top[ch][0] += hA;
-          top[ch][1] += hB;
+        const float vT = m + c[ch][0], vB = m + c[ch][3];
+        if (k == 3) {
+          top[ch][1] = vT + 4.0f;  // the + 4 of round(s / 9) = (s + 4) / 9, once per tap
+          bot[ch][1] = vB + 4.0f;
+        } else if (k == 2) {
+          top[ch][1] += vT;
+          bot[ch][1] += vB;
+          top[ch][0] = vT + 4.0f;
+          bot[ch][0] = vB + 4.0f;
+        } else if (k == 1) {
+          top[ch][1] += vT;
+          bot[ch][1] += vB;
+          top[ch][0] += vT;
+          bot[ch][0] += vB;
         } else {
-          top[ch][0] += hA;
-          top[ch][1] += hB;
+          top[ch][0] += vT;
+          bot[ch][0] += vB;
         }
       }
     }
@@ -479,170 +515,137 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
     bias[2] = px.dstBiasR - bilerp_u16((float)(a.y & 0xffff), (float)(a.w & 0xffff), (float)(b.y & 0xffff),
                                        (float)(b.w & 0xffff), w00, w01, w10, w11);
   }
-  // --- the 4x4 texel block arithmetic shared by the two block-shaped paths below. Packed fp32
-  // (v_pk_mul_f32 / v_pk_add_f32 work on register pairs): channels B and G of one offset share every
-  // instruction, and so do the R channels of the offsets dx = -1 and dx = +1 (texel columns 0 / 2 and
-  // 1 / 3 are converted straight into such pairs). Each lane of a packed operation is the same IEEE
-  // operation, in the same order, as the scalar expression it replaces. Rows are streamed two at a
-  // time: offset row iy needs texel rows iy and iy+1 only; the per-offset sums are parked and added
-  // in the reference's dx-outer / dy-inner order afterwards.
-  // xwp = (xw[0], xw[2]), xwm = xw[1]; yw[iy] per offset row.
+  // --- the 4x4 texel block arithmetic shared by the two block-shaped paths below. The block is streamed by COLUMNS
+  // (round 6): offset column ix needs texel columns ix and ix + 1 only, and computeSSD's loop runs dx outer / dy inner
+  // (DerpUtil.cpp:135-136), so the nine per-offset terms are added to the two sums the moment they exist, in the
+  // reference's order — streamed by rows (rounds 2-5) the terms came out dy-major and 18 of them were parked in
+  // registers until the end. Each operation is the same IEEE operation, in the same order, as the scalar expression it
+  // replaces; the destination patch comes from the wave's LDS window (PixCtx).
   float first = 0.f, second = 0.f;
-  // The same block in plain (unpacked) fp32 — identical operations in identical order per channel. It needs no
-  // register pairs: random proposals then fit 166 VGPRs = three waves per SIMD without a spill (192 / two waves
-  // packed), which is what a kernel that waits on cache misses wants; ping-pong, which is bound by VALU issue, is
-  // faster packed (half the instructions for the same pipe time: a packed op holds both halves of the SIMD for four
-  // cycles, v_add / v_sub / v_mul_f32 hold one half each — tools/valu_ubench.hip). A/B: profiles/r04_kernel_variants.txt
-  auto block_scalar = [&](v2f xwp, float xwm, const float (&yw)[3]) {
-    struct RowS {
-      float c[3][4];  // [channel][texel column]
-    };
-    auto unpack = [](const u4a8& a, const u4a8& b, RowS& t) {
-      t.c[0][0] = (float)(a.x & 0xffff); t.c[1][0] = (float)(a.x >> 16); t.c[2][0] = (float)(a.y & 0xffff);
-      t.c[0][1] = (float)(a.z & 0xffff); t.c[1][1] = (float)(a.z >> 16); t.c[2][1] = (float)(a.w & 0xffff);
-      t.c[0][2] = (float)(b.x & 0xffff); t.c[1][2] = (float)(b.x >> 16); t.c[2][2] = (float)(b.y & 0xffff);
-      t.c[0][3] = (float)(b.z & 0xffff); t.c[1][3] = (float)(b.z >> 16); t.c[2][3] = (float)(b.w & 0xffff);
-    };
-    const float xw3[3] = {xwp.x, xwm, xwp.y};
-    float d0s[3][3], d1s[3][3];  // [ix][iy]
-    RowS lo, hi;
-    // (block bias: rows 2 and 3 were converted once already for the box sums; an opaque copy of their words makes the
-    // compiler convert them again here instead of keeping 24 more floats alive across the bias arithmetic)
-    auto again = [](const u4a8& v) {
-      u4a8 o = v;
-      if constexpr (BLOCK_BIAS && DERP_RANDOM_RECONVERT) {
-        unsigned a = v.x, b = v.y, c = v.z, d = v.w;
-        asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-        o = (u4a8){a, b, c, d};
-      }
-      return o;
-    };
-    unpack(raw[0][0], raw[0][1], lo);
+  // (block bias: columns 2 and 3 were converted once already for the box sums; an opaque copy of their words makes the
+  // compiler convert them again here instead of keeping 24 more floats alive across the bias arithmetic)
+  u4a8 rawB[4][2];
 #pragma unroll
-    for (int iy = 0; iy < 3; ++iy) {
-      if (iy >= 1) {
-        unpack(again(raw[iy + 1][0]), again(raw[iy + 1][1]), hi);
-      } else {
-        unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
-      }
-      const float omy = 1 - yw[iy];
+  for (int r = 0; r < 4; ++r) {
+    rawB[r][0] = raw[r][0];
+    rawB[r][1] = raw[r][1];
+    if constexpr (BLOCK_BIAS && DERP_RANDOM_RECONVERT) {
+      unsigned a = raw[r][1].x, b = raw[r][1].y, c = raw[r][1].z, d = raw[r][1].w;
+      asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+      rawB[r][1] = (u4a8){a, b, c, d};
+    }
+  }
+  // Plain (unpacked) fp32: needs no register pairs. Random proposals run it (their gathers miss and the kernel wants
+  // every wave it can get); at an even number of waves per SIMD a plain fp32 op costs 2.08 cycles, i.e. the same pipe
+  // time as half a packed one (tools/valu_ubench.hip).
+  auto block_scalar = [&](const float (&xw)[3], const float (&yw)[3]) {
+    struct ColS {
+      float c[3][4];  // [channel][texel row]
+    };
+    auto unpack = [&](int k, ColS& t) {
 #pragma unroll
-      for (int ix = 0; ix < 3; ++ix) {
-        const float omx = 1 - xw3[ix];
-        const float w00 = omx * omy, w01 = xw3[ix] * omy, w10 = omx * yw[iy], w11 = xw3[ix] * yw[iy];
+      for (int r = 0; r < 4; ++r) {
+        const unsigned bg = word_bg(rawB, r, k), rr = word_r(rawB, r, k);
+        t.c[0][r] = (float)(bg & 0xffff);
+        t.c[1][r] = (float)(bg >> 16);
+        t.c[2][r] = (float)(rr & 0xffff);
+      }
+    };
+    ColS lo, hi;
+    unpack(0, lo);
+#pragma unroll
+    for (int ix = 0; ix < 3; ++ix) {
+      unpack(ix + 1, hi);
+      const float omx = 1 - xw[ix];
+#pragma unroll
+      for (int iy = 0; iy < 3; ++iy) {
+        const float omy = 1 - yw[iy];
+        const float w00 = omx * omy, w01 = xw[ix] * omy, w10 = omx * yw[iy], w11 = xw[ix] * yw[iy];
         float d0 = 0.f, d1 = 0.f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          const float v = w00 * lo.c[c][ix] + w01 * lo.c[c][ix + 1] + w10 * hi.c[c][ix] + w11 * hi.c[c][ix + 1];
-          const float db = px.patch(ix * 3 + iy, c) - __builtin_truncf(v);
+          const float v = w00 * lo.c[c][iy] + w01 * hi.c[c][iy] + w10 * lo.c[c][iy + 1] + w11 * hi.c[c][iy + 1];
+          const float db = px.patch(ix, iy, c) - __builtin_truncf(v);
           const float dn = db - bias[c];
           d0 = c == 0 ? db * db : d0 + db * db;
           d1 = c == 0 ? dn * dn : d1 + dn * dn;
         }
-        d0s[ix][iy] = d0;
-        d1s[ix][iy] = d1;
+        first += d0;
+        second += d1;
       }
       lo = hi;
     }
-#pragma unroll
-    for (int ix = 0; ix < 3; ++ix) {
-#pragma unroll
-      for (int iy = 0; iy < 3; ++iy) {
-        first += d0s[ix][iy];
-        second += d1s[ix][iy];
-      }
-    }
   };
-  auto block_packed = [&](v2f xwp, float xwm, const float (&yw)[3]) {
-    struct RowF {
-      v2f bg[4];   // (B, G) of texel columns 0..3
-      v2f rA, rB;  // R of columns (0, 2) and (1, 3)
+  // Packed fp32 (v_pk_mul_f32 / v_pk_add_f32 work on register pairs): channels B and G of one offset share every
+  // instruction, and so do the R channels of the offsets dy = -1 and dy = +1 (texel rows 0 / 2 and 1 / 3 of a column
+  // are converted straight into such pairs). ywp = (yw[0], yw[2]), ywm = yw[1]; xw[ix] per offset column.
+  auto block_packed = [&](const float (&xw)[3], v2f ywp, float ywm) {
+    struct ColF {
+      v2f bg[4];   // (B, G) of texel rows 0..3
+      v2f rE, rO;  // R of rows (0, 2) and (1, 3)
     };
-    auto unpack = [](const u4a8& a, const u4a8& b, RowF& t) {
-      t.bg[0] = bg_of(a.x);
-      t.bg[1] = bg_of(a.z);
-      t.bg[2] = bg_of(b.x);
-      t.bg[3] = bg_of(b.z);
-      t.rA = (v2f){(float)(a.y & 0xffff), (float)(b.y & 0xffff)};
-      t.rB = (v2f){(float)(a.w & 0xffff), (float)(b.w & 0xffff)};
+    auto unpack = [&](int k, ColF& t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        t.bg[r] = bg_of(word_bg(rawB, r, k));
+      }
+      t.rE = (v2f){(float)(word_r(rawB, 0, k) & 0xffff), (float)(word_r(rawB, 2, k) & 0xffff)};
+      t.rO = (v2f){(float)(word_r(rawB, 1, k) & 0xffff), (float)(word_r(rawB, 3, k) & 0xffff)};
     };
     const v2f biasBG = (v2f){bias[0], bias[1]};
-    const v2f omxp = splat2(1.0f) - xwp;
-    const float omxm = 1 - xwm;
-    float d0s[3][3], d1s[3][3];  // [ix][iy]
-    RowF lo, hi;
-    auto again = [](const u4a8& v) {  // see block_scalar
-      u4a8 o = v;
-      if constexpr (BLOCK_BIAS && DERP_RANDOM_RECONVERT) {
-        unsigned a = v.x, b = v.y, c = v.z, d = v.w;
-        asm("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
-        o = (u4a8){a, b, c, d};
-      }
-      return o;
-    };
-    unpack(raw[0][0], raw[0][1], lo);
+    const v2f omyp = splat2(1.0f) - ywp;
+    const float omym = 1 - ywm;
+    ColF lo, hi;
+    unpack(0, lo);
 #pragma unroll
-    for (int iy = 0; iy < 3; ++iy) {
-      if constexpr (BLOCK_BIAS) {
-        if (iy >= 1) {
-          unpack(again(raw[iy + 1][0]), again(raw[iy + 1][1]), hi);
-        } else {
-          unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
-        }
-      } else {
-        unpack(raw[iy + 1][0], raw[iy + 1][1], hi);
-      }
-      const float omy = 1 - yw[iy];
-      // weights of the offsets dx = -1 / +1 as pairs, of dx = 0 as scalars
-      const v2f w00p = omxp * splat2(omy), w01p = xwp * splat2(omy), w10p = omxp * splat2(yw[iy]),
-                w11p = xwp * splat2(yw[iy]);
-      const float w00m = omxm * omy, w01m = xwm * omy, w10m = omxm * yw[iy], w11m = xwm * yw[iy];
+    for (int ix = 0; ix < 3; ++ix) {
+      unpack(ix + 1, hi);
+      const float omx = 1 - xw[ix];
+      // weights of the offsets dy = -1 / +1 as pairs, of dy = 0 as scalars
+      const v2f w00p = splat2(omx) * omyp, w01p = splat2(xw[ix]) * omyp, w10p = splat2(omx) * ywp, w11p = splat2(xw[ix]) * ywp;
+      const float w00m = omx * omym, w01m = xw[ix] * omym, w10m = omx * ywm, w11m = xw[ix] * ywm;
       float bgd0[3], bgd1[3];
 #pragma unroll
-      for (int ix = 0; ix < 3; ++ix) {
-        const float w00 = ix == 1 ? w00m : ix == 0 ? w00p.x : w00p.y;
-        const float w01 = ix == 1 ? w01m : ix == 0 ? w01p.x : w01p.y;
-        const float w10 = ix == 1 ? w10m : ix == 0 ? w10p.x : w10p.y;
-        const float w11 = ix == 1 ? w11m : ix == 0 ? w11p.x : w11p.y;
-        const v2f v = splat2(w00) * lo.bg[ix] + splat2(w01) * lo.bg[ix + 1] + splat2(w10) * hi.bg[ix] +
-                      splat2(w11) * hi.bg[ix + 1];
-        const v2f db = px.patchBG[ix * 3 + iy] - trunc2(v);
+      for (int iy = 0; iy < 3; ++iy) {
+        const float w00 = iy == 1 ? w00m : iy == 0 ? w00p.x : w00p.y;
+        const float w01 = iy == 1 ? w01m : iy == 0 ? w01p.x : w01p.y;
+        const float w10 = iy == 1 ? w10m : iy == 0 ? w10p.x : w10p.y;
+        const float w11 = iy == 1 ? w11m : iy == 0 ? w11p.x : w11p.y;
+        const v2f v = splat2(w00) * lo.bg[iy] + splat2(w01) * hi.bg[iy] + splat2(w10) * lo.bg[iy + 1] +
+                      splat2(w11) * hi.bg[iy + 1];
+        const v2f db = px.patchBG(ix, iy) - trunc2(v);
         const v2f dn = db - biasBG;
         const v2f s0 = db * db, s1 = dn * dn;
         // (0 + B) + G as two plain adds over the halves of the pairs; the empty asm keeps the SLP
         // vectoriser from re-pairing them across offsets, which costs three v_mov per v_pk_add
         float t0 = s0.x + s0.y, t1 = s1.x + s1.y;
         asm("" : "+v"(t0), "+v"(t1));
-        bgd0[ix] = t0;
-        bgd1[ix] = t1;
+        bgd0[iy] = t0;
+        bgd1[iy] = t1;
       }
-      {  // R of dx = -1 / +1
-        const v2f v = w00p * lo.rA + w01p * lo.rB + w10p * hi.rA + w11p * hi.rB;
-        const v2f db = px.patchR02[iy] - trunc2(v);
+      v2f e0, e1;  // the complete terms of dy = -1 / +1
+      {  // R of dy = -1 / +1: texel rows (0, 1) and (2, 3)
+        const v2f v = w00p * lo.rE + w01p * hi.rE + w10p * lo.rO + w11p * hi.rO;
+        const v2f db = (v2f){px.patchR(ix, 0), px.patchR(ix, 2)} - trunc2(v);
         const v2f dn = db - splat2(bias[2]);
-        const v2f t0 = (v2f){bgd0[0], bgd0[2]} + db * db;
-        const v2f t1 = (v2f){bgd1[0], bgd1[2]} + dn * dn;
-        d0s[0][iy] = t0.x;
-        d0s[2][iy] = t0.y;
-        d1s[0][iy] = t1.x;
-        d1s[2][iy] = t1.y;
+        e0 = (v2f){bgd0[0], bgd0[2]} + db * db;
+        e1 = (v2f){bgd1[0], bgd1[2]} + dn * dn;
       }
-      {  // R of dx = 0: texel columns 1 and 2
-        const float v = w00m * lo.rB.x + w01m * lo.rA.y + w10m * hi.rB.x + w11m * hi.rA.y;
-        const float db = px.patchR1[iy] - __builtin_truncf(v);
+      float m0, m1;
+      {  // R of dy = 0: texel rows 1 and 2
+        const float v = w00m * lo.rO.x + w01m * hi.rO.x + w10m * lo.rE.y + w11m * hi.rE.y;
+        const float db = px.patchR(ix, 1) - __builtin_truncf(v);
         const float dn = db - bias[2];
-        d0s[1][iy] = bgd0[1] + db * db;
-        d1s[1][iy] = bgd1[1] + dn * dn;
+        m0 = bgd0[1] + db * db;
+        m1 = bgd1[1] + dn * dn;
       }
+      first += e0.x;
+      first += m0;
+      first += e0.y;
+      second += e1.x;
+      second += m1;
+      second += e1.y;
       lo = hi;
-    }
-#pragma unroll
-    for (int ix = 0; ix < 3; ++ix) {
-#pragma unroll
-      for (int iy = 0; iy < 3; ++iy) {
-        first += d0s[ix][iy];
-        second += d1s[ix][iy];
-      }
     }
   };
   // --- per-offset tap positions and weights. The reference evaluates round(x + dx) and the weight
@@ -676,19 +679,20 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
   if (DERP_UNIFORM_WEIGHTS && (!SCALAR || DERP_UNIFORM_WEIGHTS_SCALAR) && __ballot(!exact) == 0ull) {
     // every lane of the wave is in the exact case (all but ~1 % of the waves: x or y inside [2^k - 1, 2^k) or below 1
     // breaks it): ONE weight per axis serves the nine offsets, and this copy of the block says so at compile time —
-    // the weight products are formed once instead of once per offset row, and no values of the general path have to
-    // be merged in (three dozen register moves per call in the shared copy)
-    const float ywu[3] = {yw[1], yw[1], yw[1]};
+    // the four weight products are formed once, and no values of the general path have to be merged in (three dozen
+    // register moves per call in the shared copy)
+    const float xwu[3] = {xw[1], xw[1], xw[1]};
     if constexpr (SCALAR) {
-      block_scalar(splat2(xw[1]), xw[1], ywu);
+      const float ywu[3] = {yw[1], yw[1], yw[1]};
+      block_scalar(xwu, ywu);
     } else {
-      block_packed(splat2(xw[1]), xw[1], ywu);
+      block_packed(xwu, splat2(yw[1]), yw[1]);
     }
   } else if (regular) {
     if constexpr (SCALAR) {
-      block_scalar((v2f){xw[0], xw[2]}, xw[1], yw);
+      block_scalar(xw, yw);
     } else {
-      block_packed((v2f){xw[0], xw[2]}, xw[1], yw);
+      block_packed(xw, (v2f){yw[0], yw[2]}, yw[1]);
     }
   } else if (DERP_MIX_HOT_ONLY) {
     first = second = 0.f;
@@ -708,10 +712,13 @@ __device__ __forceinline__ SsdPair ssd_arith(const LevelView& V, const PixCtx& p
         const float p01[3] = {(float)q01.x, (float)q01.y, (float)q01.z};
         const float p10[3] = {(float)q10.x, (float)q10.y, (float)q10.z};
         const float p11[3] = {(float)q11.x, (float)q11.y, (float)q11.z};
+        // the patch texel of this offset (dynamic window index: the loop is not unrolled)
+        const v2f pbg = px.winBG[iy * kWinW + ix];
+        const float pch[3] = {pbg.x, pbg.y, px.winR[iy * kWinW + ix]};
         float d0 = 0.f, d1 = 0.f;
         for (int c = 0; c < 3; ++c) {
           const float cs = bilerp_u16(p00[c], p01[c], p10[c], p11[c], w00, w01, w10, w11);
-          const float db = px.patch(ix * 3 + iy, c) - cs;
+          const float db = pch[c] - cs;
           const float dn = db - bias[c];
           d0 += db * db;
           d1 += dn * dn;
@@ -863,7 +870,9 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       pend = vis;
       pendSlot = slot(s, own);
       if (__ballot(vis) != 0ull) {
-        const float sx = (float)(pn.x * (double)V.W), sy = (float)(pn.y * (double)V.H);
+        // (the level size as doubles from the kernel arguments: converted here, the pair is hoisted into vector registers
+        // and is what the allocator spills first)
+        const float sx = (float)(pn.x * V.Wd), sy = (float)(pn.y * V.Hd);
         // pDstSrc = getPixelBilinear(dstProjWarp, pSrc)
         const float xf = roundf(sx), yf = roundf(sy);
         const int xi = (int)xf, yi = (int)yf;
@@ -924,7 +933,7 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
 
 // gather the per-pixel constants of computeCost: dst ray, 3x3 dst patch, dst bias, variance
 template <bool WITH_RAY = true>
-__device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, int x, int y, PixCtx& px) {
+__device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, int x, int y, const PatchWin* win, PixCtx& px) {
   const Cam& cd = V.camsDst[d];
   px.rayO = {cd.pos[0], cd.pos[1], cd.pos[2]};
   // the ray direction of the pixel centre (Camera::rig of p = ((x + .5) / W, (y + .5) / H): undistort's Newton
@@ -936,22 +945,10 @@ __device__ __forceinline__ void load_pixctx(const LevelView& V, int d, int own, 
     const size_t i = (size_t)d * n + (size_t)y * V.W + x;
     px.rayD = {V.rayDir[i], V.rayDir[V.rayStride + i], V.rayDir[2 * V.rayStride + i]};
   }
-  const ushort4* col = V.srcColor + (size_t)own * n;
-#pragma unroll
-  for (int ix = 0; ix < 3; ++ix) {
-#pragma unroll
-    for (int iy = 0; iy < 3; ++iy) {
-      const ushort4 q = col[(size_t)(y + iy - 1) * V.W + (x + ix - 1)];
-      px.patchBG[ix * 3 + iy] = (v2f){(float)q.x, (float)q.y};
-      if (ix == 1) {
-        px.patchR1[iy] = (float)q.z;
-      } else if (ix == 0) {
-        px.patchR02[iy].x = (float)q.z;
-      } else {
-        px.patchR02[iy].y = (float)q.z;
-      }
-    }
-  }
+  // the 3x3 patch: the lane's corner of the wave's window (patch_window_fill)
+  const int corner = (int)((threadIdx.x & 63) >> 3) * kWinW + (int)(threadIdx.x & 7);
+  px.winBG = win->bg + corner;
+  px.winR = win->r + corner;
   const ushort4 b = V.ownBias[(size_t)own * n + (size_t)y * V.W + x];
   px.dstBiasBG = (v2f){(float)b.x, (float)b.y};
   px.dstBiasR = (float)b.z;
@@ -1458,14 +1455,18 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int lane = threadIdx.x & 63;
   const int sx = (int)(blockIdx.x % (unsigned)tilesX), sy = (int)(blockIdx.x / (unsigned)tilesX);
   const int x = 1 + sx * 8 + (lane & 7), y = 1 + sy * 8 + (lane >> 3);
+  // the wave's 10x10 window of destination colours (PatchWin): filled by all 64 lanes before anything diverges
+  __shared__ PatchWin patchWin[DERP_COST_BLOCK / 64];
+  PatchWin* win = &patchWin[threadIdx.x >> 6];
+  patch_window_fill(V, V.dst2src[d], x - (int)(threadIdx.x & 7), y - (int)((threadIdx.x & 63) >> 3), win);
 #if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
   __shared__ double atanLut[kAtanLutDoubles];
   atan_lut_fill(atanLut);
-  __syncthreads();
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
 #else
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
 #endif
+  __syncthreads();
   unsigned nCost = 0, nPair = 0;
   if (x <= iw && y <= ih) {
     const int own = V.dst2src[d];
@@ -1477,7 +1478,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     float2 r = make_float2(__builtin_nanf(""), __builtin_nanf(""));
     if (fov && fg && closer) {
       PixCtx px;
-      load_pixctx(V, d, own, x, y, px);
+      load_pixctx(V, d, own, x, y, win, px);
       r = compute_cost<DERP_COST_SSD_SCALAR != 0>(V, dl, own, px, disparity, pairs, nPair);
       ++nCost;
     }
@@ -1607,55 +1608,77 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
   const int d = V.dst0 + dl;
   int x, y;
   tile_pixel(DERP_RANDOM_SWIZZLE ? xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0) : (int)blockIdx.x, tilesX, x, y);
+  // the wave's 10x10 window of destination colours (PatchWin): filled by all 64 lanes before anything diverges
+  __shared__ PatchWin patchWin[DERP_COST_BLOCK / 64];
+  PatchWin* win = &patchWin[threadIdx.x >> 6];
+  patch_window_fill(V, V.dst2src[d], x - (int)(threadIdx.x & 7), y - (int)((threadIdx.x & 63) >> 3), win);
 #if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
   __shared__ double atanLut[kAtanLutDoubles];
   atan_lut_fill(atanLut);
-  __syncthreads();
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
 #else
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
 #endif
+  __syncthreads();
   unsigned nCost = 0, nPair = 0, nSlots = 0, nSlotsFirst = 0;
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
     const int own = V.dst2src[d];
-    const size_t n = (size_t)V.W * V.H, idx = (size_t)y * V.W + x;
+    // per-destination planes (wave-uniform bases) and a 32-bit pixel index, as in k_ping_pong
+    const size_t n = (size_t)V.W * V.H;
+    const unsigned idx = (unsigned)y * (unsigned)V.W + (unsigned)x;
     float* disp = V.disparity + (size_t)d * n;
-    if (V.fovMask[(size_t)d * n + idx]) {
-      if (!V.srcFg[(size_t)own * n + idx]) {
-        disp[idx] = V.bgDisp[(size_t)d * n + idx];
+    if ((V.fovMask + (size_t)d * n)[idx]) {
+      if (!(V.srcFg + (size_t)own * n)[idx]) {
+        disp[idx] = (V.bgDisp + (size_t)d * n)[idx];
       } else if (random_gate(V, d, own, idx)) {
         PixCtx px;
-        load_pixctx<!DERP_RANDOM_RELOAD_RAY>(V, d, own, x, y, px);
+        load_pixctx<!DERP_RANDOM_RELOAD_RAY>(V, d, own, x, y, win, px);
         const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
+        // What the proposal loop carries per lane: the pixel index, the current disparity / cost / confidence / pair count,
+        // the acceptance threshold, the amplitude, the engine state, the pair counter; the lower bound of the range is
+        // read again per proposal.
+        // One copy of computeCost serves the evaluation of the current disparity (i = -1) and the proposals: the kernel's
+        // code is half the size it was with two inlined copies (45 KB against a 64 KB instruction cache).
         float currDisp = disp[idx];
-        unsigned before = nPair;
-        float2 cur = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, currDisp, pairs, nPair, cull, (unsigned)idx, &nSlotsFirst);
-        ++nCost;
-        unsigned currPairs = nPair - before;
-        float currCost = cur.x, currConf = cur.y;
-        const float costThresh = fminf(0.5f * currCost, 5.0f);  // kRandomPropMaxCost
-        const float minDisp = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : (1.0f / V.maxDepthM);
+        float currCost = 0.f, currConf = 0.f, costThresh = 0.f, amplitude = 0.f;
+        unsigned currPairs = 0;  // (no store inside the loop: a store's acknowledgement would sit in front of every later load's wait)
         const float maxDisp = 1.0f / V.minDepthM;
-        float amplitude = (maxDisp - minDisp) / 2.0f;
-        uint32_t state = (uint32_t)rank[(size_t)d * n + idx];  // minstd_rand0 positioned by k_row_rank
-        for (int i = 0; i < V.randomProposals; ++i) {
-          const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
-          const float propDisp = minstd_uniform(state, lo, hi);
-          before = nPair;
-          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, propDisp, pairs, nPair, cull, (unsigned)idx, &nSlots);
-          ++nCost;
-          if (pr.x < currCost && pr.x < costThresh) {
+        uint32_t state = (uint32_t)(rank + (size_t)d * n)[idx];  // minstd_rand0 positioned by k_row_rank
+        for (int i = -1; i < V.randomProposals; ++i) {
+          unsigned pi = idx;
+          asm("" : "+v"(pi) : "s"(i));  // (opaque per proposal: the loads below stay inside the loop)
+          const float minDisp = V.hasFg ? (V.bgDisp + (size_t)d * n)[pi] : (1.0f / V.maxDepthM);
+          float propDisp = currDisp;
+          if (i >= 0) {
+            const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
+            propDisp = minstd_uniform(state, lo, hi);
+          }
+          unsigned np = 0;
+          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, propDisp, pairs, np, cull, pi, i < 0 ? &nSlotsFirst : &nSlots);
+          nPair += np;
+          bool take;
+          if (i < 0) {
+            costThresh = fminf(0.5f * pr.x, 5.0f);  // kRandomPropMaxCost
+            amplitude = (maxDisp - minDisp) / 2.0f;
+            take = true;
+          } else {
+            take = pr.x < currCost && pr.x < costThresh;
+            if (take) {
+              amplitude /= 2.0f;
+            }
+          }
+          if (take) {
             currCost = pr.x;
             currDisp = propDisp;
             currConf = pr.y;
-            currPairs = nPair - before;
-            amplitude /= 2.0f;
+            currPairs = np;
           }
         }
+        (V.confidence + (size_t)d * n)[idx] = currConf;
+        (V.pairCount + (size_t)d * n)[idx] = (uint8_t)currPairs;
+        nCost = 1u + (unsigned)max(V.randomProposals, 0);
         disp[idx] = currDisp;
-        V.cost[(size_t)d * n + idx] = currCost;
-        V.confidence[(size_t)d * n + idx] = currConf;
-        V.pairCount[(size_t)d * n + idx] = (uint8_t)currPairs;
+        (V.cost + (size_t)d * n)[idx] = currCost;
       }
     }
   }
@@ -1679,15 +1702,20 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int d = V.dst0 + dl;
   int x, y;
   tile_pixel(xcd_swizzle(blockIdx.x, gridDim.x, V.xcdRotate ? d : 0), tilesX, x, y);
+  // the wave's 10x10 window of destination colours (PatchWin): filled by all 64 lanes before anything diverges
+  __shared__ PatchWin patchWin[DERP_COST_BLOCK / 64];
+  PatchWin* win = &patchWin[threadIdx.x >> 6];
+  patch_window_fill(V, V.dst2src[d], x - (int)(threadIdx.x & 7), y - (int)((threadIdx.x & 63) >> 3), win);
 #if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
   __shared__ double atanLut[kAtanLutDoubles];
   atan_lut_fill(atanLut);
-  __syncthreads();
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
 #else
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
 #endif
-  unsigned nCost = 0, nPair = 0, nMemo = 0;
+  __syncthreads();
+  // per-lane counters in one register: pairs (bits 0..15: <= 9 * 31), cost evaluations (16..23: <= 9), memoised (24..)
+  unsigned counts = 0;
   if (x < V.W && y < V.H) {
     const int own = V.dst2src[d];
     // per-destination planes (wave-uniform bases) and a 32-bit pixel index: the loads take the scalar-base + 32-bit
@@ -1707,34 +1735,40 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
         outDisp = V.bgDisp[(size_t)d * n + idx];
       } else if (!(V.srcVar[(size_t)own * n + idx] < V.varNoiseFloor)) {
         PixCtx px;
-        load_pixctx<!DERP_PP_RELOAD_RAY>(V, d, own, x, y, px);
+        load_pixctx<!DERP_PP_RELOAD_RAY>(V, d, own, x, y, win, px);
         const unsigned cull = DERP_SOURCE_CULL ? behind_sources(V, d, idx) : 0u;
         float bestCost = __builtin_inff();
         float bestDisp = outDisp;
-        const float bg = V.hasFg ? V.bgDisp[(size_t)d * n + idx] : 0.f;
+        // what the candidate loop carries per lane: the pixel (x | y << 16), the best candidate so far, the counters.
+        // Everything else is derived again per candidate from an opaque copy of `xy` (four plain instructions) instead
+        // of riding through computeCost's registers: x, y, the pixel index, the background disparity.
+        const unsigned xy = (unsigned)x | ((unsigned)y << 16);
         for (int k = 0; k < 9; ++k) {
-          const int xx = min(max(x + kCandidates[k][0], 0), V.W - 1);
-          const int yy = min(max(y + kCandidates[k][1], 0), V.H - 1);
+          unsigned q = xy;
+          asm("" : "+v"(q) : "s"(k));
+          const int px0 = (int)(q & 0xffffu), py0 = (int)(q >> 16);
+          const unsigned pidx = (unsigned)py0 * (unsigned)V.W + (unsigned)px0;
+          const int xx = min(max(px0 + kCandidates[k][0], 0), V.W - 1);
+          const int yy = min(max(py0 + kCandidates[k][1], 0), V.H - 1);
           const unsigned j = (unsigned)yy * (unsigned)V.W + (unsigned)xx;
           if (fov[j]) {
             const float cand = disp[j];
+            const float bg = V.hasFg ? (V.bgDisp + (size_t)d * n)[pidx] : 0.f;
             if (cand >= bg && chg[j]) {
               float2 r;
               // Candidate (0,0) is the pixel's own disparity. In the first iteration, where random
               // proposals evaluated this pixel, computeCost(own disparity) is exactly the value they
               // left in cost / confidence (a pure function of the same arguments): reuse it.
-              // (the opaque copy of the index keeps these three addresses out of the registers the loop carries)
-              unsigned mi = idx;
-              asm("" : "+v"(mi) : "v"(cand));  // (not volatile, tied to the candidate: see compute_cost)
-              const float memoConf = (k == 0 && useMemo) ? (V.confidence + (size_t)d * n)[mi] : 0.0f;
+              const float memoConf = (k == 0 && useMemo) ? (V.confidence + (size_t)d * n)[pidx] : 0.0f;
               if (memoConf != 0.0f) {
-                r = make_float2((V.cost + (size_t)d * n)[mi], memoConf);
-                nPair += (V.pairCount + (size_t)d * n)[mi];
-                ++nMemo;
+                r = make_float2((V.cost + (size_t)d * n)[pidx], memoConf);
+                counts += (unsigned)(V.pairCount + (size_t)d * n)[pidx] + (1u << 24);
               } else {
-                r = compute_cost<DERP_COST_SSD_SCALAR != 0, false, DERP_PP_RELOAD_RAY != 0>(V, dl, own, px, cand, pairs, nPair, cull, idx);
+                unsigned np = 0;
+                r = compute_cost<DERP_COST_SSD_SCALAR != 0, false, DERP_PP_RELOAD_RAY != 0>(V, dl, own, px, cand, pairs, np, cull, pidx);
+                counts += np;
               }
-              ++nCost;
+              counts += 1u << 16;
               if (r.x < bestCost) {
                 bestCost = r.x;
                 bestDisp = cand;
@@ -1749,7 +1783,8 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     dispRes[idx] = outDisp;
     costRes[idx] = outCost;
   }
-  flush_counters(V, nCost, nPair);
+  unsigned nMemo = counts >> 24;
+  flush_counters(V, (counts >> 16) & 0xffu, counts & 0xffffu);
   for (int off = 32; off > 0; off >>= 1) {
     nMemo += __shfl_down(nMemo, off);
   }
@@ -1879,19 +1914,23 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   const int dl = d - V.dst0;
   int x, y;
   tile_pixel(blockIdx.x, tilesX, x, y);
+  // the wave's 10x10 window of destination colours (PatchWin): filled by all 64 lanes before anything diverges
+  __shared__ PatchWin patchWin[DERP_COST_BLOCK / 64];
+  PatchWin* win = &patchWin[threadIdx.x >> 6];
+  patch_window_fill(V, V.dst2src[d], x - (int)(threadIdx.x & 7), y - (int)((threadIdx.x & 63) >> 3), win);
 #if DERP_ATAN_LUT && DERP_LEAN_PROJ && defined(__HIP_DEVICE_COMPILE__)
   __shared__ double atanLut[kAtanLutDoubles];
   atan_lut_fill(atanLut);
-  __syncthreads();
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, atanLut};
 #else
   LdsPairs pairs{ldsPairs + threadIdx.x, (int)blockDim.x, nullptr};
 #endif
+  __syncthreads();
   unsigned nCost = 0, nPair = 0;
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
     const int own = V.dst2src[d];
     PixCtx px;
-    load_pixctx(V, d, own, x, y, px);
+    load_pixctx(V, d, own, x, y, win, px);
     const float2 r = compute_cost<DERP_COST_SSD_SCALAR != 0>(V, dl, own, px, dispIn[(size_t)y * V.W + x], pairs, nPair);
     ++nCost;
     costOut[(size_t)y * V.W + x] = r.x;
