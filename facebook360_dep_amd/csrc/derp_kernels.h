@@ -801,10 +801,27 @@ __device__ __forceinline__ unsigned behind_sources(const LevelView& V, int d, si
 // instead of living in six registers across the candidate loop — where the allocator parked it in scratch (one store per
 // pixel, one load per candidate: 2.4 GB of scratch writes per level-0 launch at config 2, round 4). The opaque copy of
 // the index keeps the loads inside the loop.
+// developer build (-DDERP_PHASE_TIMERS=1|2): wave cycles (s_memtime) spent in computeCost's phases, reported through the
+// kernel's counter slots INSTEAD of the cost / pair counts: =1 -> [0] projection + taps, [1] SSD walk, [3] selection;
+// =2 -> [0] the whole kernel body, [1] everything outside computeCost. tools/phase_timers.py prints them.
+#ifndef DERP_PHASE_TIMERS
+#define DERP_PHASE_TIMERS 0
+#endif
+struct PhaseTimers {
+  unsigned proj = 0, ssd = 0, select = 0, inside = 0;  // (32 bits: a wave lives < 2^32 cycles)
+};
+__device__ __forceinline__ unsigned phase_clock() {
+#if DERP_PHASE_TIMERS
+  return (unsigned)__builtin_amdgcn_s_memtime();
+#else
+  return 0u;
+#endif
+}
 template <bool SCALAR = false, bool RANDOM = false, bool RELOAD_RAY = false>
 __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int own, const PixCtx& px, float disparity,
                                                LdsPairs& pairs, unsigned& nPair, unsigned cull = 0, unsigned pix = 0,
-                                               unsigned* slots = nullptr) {
+                                               unsigned* slots = nullptr, PhaseTimers* tm = nullptr) {
+  const unsigned tc0 = phase_clock();
   const double depth = (double)(1.0f / disparity);
   D3 rayD = px.rayD;
   if constexpr (RELOAD_RAY) {
@@ -891,6 +908,7 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       consume();
     }
   }
+  const unsigned tc1 = phase_clock();
   const int ssdCount = __popc(mask);
   nPair += ssdCount;
 #ifdef DERP_COUNT_UNION  // developer measurement: SSD iterations the WAVE walks (its lanes' union) per active lane
@@ -916,6 +934,7 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       }
     }
   }
+  const unsigned tc2 = phase_clock();
   keep = max(keep, ssdCount - 2);
   GccSelect<LdsPairs> sel(pairs);
 #ifndef DERP_ABLATE_NO_SELECT
@@ -928,6 +947,12 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
   cost /= (float)keep;
   const float trustCoef = 1.0f / (float)keep;
   const float costFinal = cost * trustCoef / px.confidence;
+#if DERP_PHASE_TIMERS
+  if (tm) {
+    const unsigned tc3 = phase_clock();
+    tm->proj += tc1 - tc0, tm->ssd += tc2 - tc1, tm->select += tc3 - tc2, tm->inside += tc3 - tc0;
+  }
+#endif
   return make_float2(costFinal, px.confidence);
 }
 
@@ -1621,6 +1646,8 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
 #endif
   __syncthreads();
   unsigned nCost = 0, nPair = 0, nSlots = 0, nSlotsFirst = 0;
+  PhaseTimers tm;
+  const unsigned tk0 = phase_clock();
   if (x >= 1 && y >= 1 && x < V.W - 1 && y < V.H - 1) {
     const int own = V.dst2src[d];
     // per-destination planes (wave-uniform bases) and a 32-bit pixel index, as in k_ping_pong
@@ -1654,7 +1681,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
             propDisp = minstd_uniform(state, lo, hi);
           }
           unsigned np = 0;
-          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, propDisp, pairs, np, cull, pi, i < 0 ? &nSlotsFirst : &nSlots);
+          const float2 pr = compute_cost<DERP_RANDOM_SSD_SCALAR != 0, true, DERP_RANDOM_RELOAD_RAY != 0>(V, dl, own, px, propDisp, pairs, np, cull, pi, i < 0 ? &nSlotsFirst : &nSlots, &tm);
           nPair += np;
           bool take;
           if (i < 0) {
@@ -1682,6 +1709,15 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
       }
     }
   }
+#if DERP_PHASE_TIMERS
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned body = phase_clock() - tk0;
+    atomicAdd(&V.counters[0], (unsigned long long)(DERP_PHASE_TIMERS == 1 ? tm.proj : body));
+    atomicAdd(&V.counters[1], (unsigned long long)(DERP_PHASE_TIMERS == 1 ? tm.ssd : body - tm.inside));
+    atomicAdd(&V.counters[3], (unsigned long long)(DERP_PHASE_TIMERS == 1 ? tm.select : 0u));
+  }
+  return;
+#endif
   flush_counters(V, nCost, nPair);
 #ifdef DERP_COUNT_UNION
   atomicAdd(&V.counters[3], (unsigned long long)nSlots);       // random candidates: lane-slots the waves walked
@@ -1716,6 +1752,8 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   __syncthreads();
   // per-lane counters in one register: pairs (bits 0..15: <= 9 * 31), cost evaluations (16..23: <= 9), memoised (24..)
   unsigned counts = 0;
+  PhaseTimers tm;
+  const unsigned tk0 = phase_clock();
   if (x < V.W && y < V.H) {
     const int own = V.dst2src[d];
     // per-destination planes (wave-uniform bases) and a 32-bit pixel index: the loads take the scalar-base + 32-bit
@@ -1765,7 +1803,7 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
                 counts += (unsigned)(V.pairCount + (size_t)d * n)[pidx] + (1u << 24);
               } else {
                 unsigned np = 0;
-                r = compute_cost<DERP_COST_SSD_SCALAR != 0, false, DERP_PP_RELOAD_RAY != 0>(V, dl, own, px, cand, pairs, np, cull, pidx);
+                r = compute_cost<DERP_COST_SSD_SCALAR != 0, false, DERP_PP_RELOAD_RAY != 0>(V, dl, own, px, cand, pairs, np, cull, pidx, nullptr, &tm);
                 counts += np;
               }
               counts += 1u << 16;
@@ -1783,6 +1821,15 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
     dispRes[idx] = outDisp;
     costRes[idx] = outCost;
   }
+#if DERP_PHASE_TIMERS
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned body = phase_clock() - tk0;
+    atomicAdd(&V.counters[0], (unsigned long long)(DERP_PHASE_TIMERS == 1 ? tm.proj : body));
+    atomicAdd(&V.counters[1], (unsigned long long)(DERP_PHASE_TIMERS == 1 ? tm.ssd : body - tm.inside));
+    atomicAdd(&V.counters[3], (unsigned long long)(DERP_PHASE_TIMERS == 1 ? tm.select : 0u));
+  }
+  return;
+#endif
   unsigned nMemo = counts >> 24;
   flush_counters(V, (counts >> 16) & 0xffu, counts & 0xffffu);
   for (int off = 32; off > 0; off >>= 1) {
