@@ -227,6 +227,12 @@ def main():
         raise SystemExit("bench.py: --gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         return launch_ranks(args)
+    # stdout carries the one JSON line and nothing else: whatever a library prints there (Gloo's "Rank 0 is connected"
+    # banner, a runtime warning) goes to stderr — file descriptor 1 is pointed at 2 for the run, the line is written to
+    # the saved descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np  # noqa: F401
     import torch
 
@@ -344,7 +350,11 @@ def main():
     xs = runner.stats()
     exch = {"bytes_received_per_step": xs["bytes_received"] // max(args.steps, 1),
             "bytes_sent_per_step": xs["bytes_sent"] // max(args.steps, 1),
-            "ms_per_step_on_stream": round(xs["exchange_ms"] / max(args.steps, 1), 3)}
+            "ms_per_step_on_stream": round(xs["exchange_ms"] / max(args.steps, 1), 3),
+            # of which the compute stream stood still for (the rest ran beside the filter of the frames whose windows are
+            # local to the rank); hidden_frac = 1 - exposed / on_stream
+            "ms_per_step_exposed": round(xs["exchange_exposed_ms"] / max(args.steps, 1), 3),
+            "hidden_frac": (round(1.0 - xs["exchange_exposed_ms"] / xs["exchange_ms"], 3) if xs["exchange_ms"] > 0 else None)}
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, exch)
@@ -506,7 +516,8 @@ def main():
     runner.close()
     g.close()
     if rank == 0:
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.destroy_process_group()
 

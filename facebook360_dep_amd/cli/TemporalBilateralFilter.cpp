@@ -101,13 +101,15 @@ static bool run_on_sequence_engine(Flags& F, const std::vector<derp_camera_desc>
   DerpJob J(G);
   J.filterOnly = true;
   J.setup_host();
+  // every frame of A..B stays in HBM for the level (colour 8 B, raw + filtered disparity 8 B, masks 2 B per pixel and
+  // camera, + the window-only frames' scratch): a chunk that would not fit comfortably takes the frame-by-frame path,
+  // which holds one window at a time. First against a cap that needs no device (DERP_TBF_HBM_BUDGET_GB), then — once the
+  // context exists — against what the device really has free.
+  const double residentBytes = (double)(B - A + 1) * J.D * (double)J.npx(level) * 20.0;
   {
-    // every frame of A..B stays in HBM for the level (colour 8 B, raw + filtered disparity 8 B, masks 2 B per pixel and
-    // camera): a chunk that would not fit comfortably takes the frame-by-frame path, which holds one window at a time
-    const double bytes = (double)(B - A + 1) * J.D * (double)J.npx(level) * 20.0;
     const char* e = getenv("DERP_TBF_HBM_BUDGET_GB");
-    if (bytes > (e ? atof(e) : 128.0) * 1e9) {
-      LOG_INFO(fmt("frames %06d..%06d of level %d need %.1f GB resident: filtering frame by frame instead", A, B, level, bytes / 1e9));
+    if (residentBytes > (e ? atof(e) : 128.0) * 1e9) {
+      LOG_INFO(fmt("frames %06d..%06d of level %d need %.1f GB resident: filtering frame by frame instead", A, B, level, residentBytes / 1e9));
       return false;
     }
   }
@@ -127,6 +129,17 @@ static bool run_on_sequence_engine(Flags& F, const std::vector<derp_camera_desc>
   derp_ctx* ctx = J.ctx;
   LOG_INFO(fmt("-- start-up: flags + rig + input check %.3fs, HIP runtime + context %.3fs (images decoding since %.3fs)", tHost,
                total.s() - tHost, tHost));
+  {
+    uint64_t freeB = 0, totalB = 0;
+    DERP_OK(ctx, derp_device_memory(ctx, &freeB, &totalB));
+    if (residentBytes > 0.85 * (double)freeB) {  // a smaller or shared device: the window-at-a-time path still fits
+      LOG_INFO(fmt("frames %06d..%06d of level %d need %.1f GB resident, the device has %.1f GB free: filtering frame by frame "
+                   "instead", A, B, level, residentBytes / 1e9, (double)freeB / 1e9));
+      derp_destroy(ctx);
+      J.ctx = nullptr;
+      return false;
+    }
+  }
   derp_seq_options so;
   derp_seq_options_default(&so);
   so.time_radius = R;

@@ -142,6 +142,22 @@ struct derp_ctx {
   DevBuf spiral;
   int spiralN = 0, spiralRadius = -1;
 
+  // Work lanes (round 6): a second, third ... working set + stream for processLevel of ANOTHER frame of a sequence at the
+  // same coarse level (derp_seq_level_compute). The frames of a level are independent, and at the coarse levels one
+  // frame's kernels fill a fraction of the chip (level 6 of the 16-camera rig: 784 waves for 4096 wave slots) and are
+  // bound by their own serial latency — on lanes the frames' kernels overlap. A lane holds everything processLevel writes
+  // per frame; the rig-only tables of the level (projWarp, projWarpInv, rayDir, behind, resampling tables) stay shared.
+  struct WorkLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    DevBuf srcVar, ownBias, fovMask, maskAnd, disparity, cost, confidence, dispRes, costRes, changed, tmpF, rank, mismatchMask,
+        pairCount, tileSeen, projColor, projBias, projColorT, bruteCost, bruteConf, lanczosTmp, staging, stagingB;
+    int colorTablesCleanLevel = -1;
+  };
+  std::vector<WorkLane*> lanes;
+  hipEvent_t laneReady = nullptr;  // recorded on the main stream behind what the lanes' frames depend on
+  int activeLane = -1;             // the lane whose members are swapped in (-1: the context's own)
+
   bool profiling = false;
   bool noMemo = false;  // DERP_NO_MEMO (developer switch), read once in derp_create
   // waves per SIMD of the random-proposal / ping-pong kernels (0 = what their registers and LDS allow: four up to 16
@@ -1008,6 +1024,74 @@ int select_frame(derp_ctx* c, int slot) {
   return 0;
 }
 
+// exchange the context's per-frame working set (and stream) with lane `i`'s: applied twice it is the identity
+void lane_swap(derp_ctx* c, int i) {
+  derp_ctx::WorkLane& w = *c->lanes[i];
+  std::swap(c->stream, w.stream);
+  std::swap(c->colorTablesCleanLevel, w.colorTablesCleanLevel);
+  DevBuf* mine[] = {&c->srcVar, &c->ownBias, &c->fovMask, &c->maskAnd, &c->disparity, &c->cost, &c->confidence, &c->dispRes,
+                    &c->costRes, &c->changed, &c->tmpF, &c->rank, &c->mismatchMask, &c->pairCount, &c->tileSeen, &c->projColor,
+                    &c->projBias, &c->projColorT, &c->bruteCost, &c->bruteConf, &c->lanczosTmp, &c->staging, &c->stagingB};
+  DevBuf* theirs[] = {&w.srcVar, &w.ownBias, &w.fovMask, &w.maskAnd, &w.disparity, &w.cost, &w.confidence, &w.dispRes,
+                      &w.costRes, &w.changed, &w.tmpF, &w.rank, &w.mismatchMask, &w.pairCount, &w.tileSeen, &w.projColor,
+                      &w.projBias, &w.projColorT, &w.bruteCost, &w.bruteConf, &w.lanczosTmp, &w.staging, &w.stagingB};
+  for (size_t k = 0; k < sizeof(mine) / sizeof(mine[0]); ++k) {
+    std::swap(*mine[k], *theirs[k]);
+  }
+}
+
+// lanes 0 .. count - 1 exist and hold working buffers for a level of `n` pixels
+int lanes_prepare(derp_ctx* c, int count, size_t n) {
+  while ((int)c->lanes.size() < count) {
+    auto* w = new derp_ctx::WorkLane();
+    c->lanes.push_back(w);
+    if (hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) {
+      return fail(c, "work lane: hipStreamCreate / hipEventCreate failed");
+    }
+  }
+  if (!c->laneReady) {
+    HIPCHK(c, hipEventCreateWithFlags(&c->laneReady, hipEventDisableTiming));
+  }
+  for (int i = 0; i < count; ++i) {
+    derp_ctx::WorkLane& w = *c->lanes[i];
+    ALLOC(c, w.srcVar, n * c->S * sizeof(float));
+    ALLOC(c, w.ownBias, n * c->S * sizeof(ushort4));
+    ALLOC(c, w.fovMask, n * c->D);
+    ALLOC(c, w.maskAnd, n * c->D);
+    for (DevBuf* b : {&w.disparity, &w.cost, &w.confidence, &w.dispRes, &w.costRes, &w.tmpF, &w.rank}) {
+      ALLOC(c, *b, n * c->D * sizeof(float));
+    }
+    ALLOC(c, w.changed, n * c->D);
+    ALLOC(c, w.mismatchMask, n * c->D);
+    ALLOC(c, w.pairCount, n * c->D);
+  }
+  return 0;
+}
+
+// processLevel of the frame in slot `slot` on lane `i` (i < 0: on the context's own working set and stream). The lane's
+// stream first waits for c->laneReady.
+int process_level_on_lane(derp_ctx* c, int i, int slot, int level) {
+  if (i < 0) {
+    TRY(select_frame(c, slot));
+    return process_level(c, level);
+  }
+  HIPCHK(c, hipStreamWaitEvent(c->lanes[i]->stream, c->laneReady, 0));
+  lane_swap(c, i);
+  c->activeLane = i;
+  int rc = select_frame(c, slot);
+  if (!rc) {
+    rc = process_level(c, level);
+  }
+  if (!rc && hipEventRecord(c->lanes[i]->done, c->stream) != hipSuccess) {
+    rc = fail(c, "work lane: hipEventRecord failed");
+  }
+  lane_swap(c, i);
+  c->activeLane = -1;
+  c->cur = -1;  // the context's own working buffers do not hold that frame's level
+  return rc;
+}
+
 // temporalJointBilateralFilter (TemporalBilateralFilter.h:126-215) of `planes` planes over a window of n frames,
 // frame `centre` being the one filtered: one launch per kMaxTemporalFrames frames, the sums carried between them
 int temporal_launch(derp_ctx* c, const void* const* guides, const float* const* images, const uint8_t* const* masks, int n,
@@ -1159,6 +1243,13 @@ int derp_create(derp_ctx** out, int device, const derp_camera_desc* src, int n_s
     if (!found) {
       return bail(std::string("destination camera ") + dst[i].id + " is not a source camera");
     }
+    // The reference's destinations ARE rig cameras (filterDestinations, Derp.cpp:42-70, keeps a subset of the rig), and
+    // k_reproject_bias relies on it: projWarpInv(d, s) is read from projWarp(ds, own) when s is destination ds. A
+    // descriptor that shares an id with a source but not its intrinsics / pose would silently warp with the wrong camera.
+    if (memcmp(&c->camsDstH[i], &c->camsSrcH[c->dst2srcH[i]], sizeof(Cam)) != 0) {
+      return bail(std::string("destination camera ") + dst[i].id + " differs from the source camera of the same id "
+                  "(destinations must be cameras of the source rig, as filterDestinations makes them)");
+    }
   }
   if (c->camsSrc.ensure(sizeof(Cam) * n_src) || c->camsDst.ensure(sizeof(Cam) * n_dst) ||
       c->dst2src.ensure(sizeof(int) * n_dst) || c->counters.ensure(sizeof(unsigned long long) * ST_COUNT * kMaxLevels * 4)) {
@@ -1215,6 +1306,20 @@ void derp_destroy(derp_ctx* c) {
   c->copyStaging.release();
   for (DevBuf* b : {&c->cnVert, &c->cnRgba, &c->cnZ, &c->cnAcc, &c->cnOut, &c->cnBig, &c->cnNBig}) {
     b->release();
+  }
+  for (derp_ctx::WorkLane* w : c->lanes) {
+    (void)hipStreamSynchronize(w->stream);
+    for (DevBuf* b : {&w->srcVar, &w->ownBias, &w->fovMask, &w->maskAnd, &w->disparity, &w->cost, &w->confidence, &w->dispRes,
+                      &w->costRes, &w->changed, &w->tmpF, &w->rank, &w->mismatchMask, &w->pairCount, &w->tileSeen, &w->projColor,
+                      &w->projBias, &w->projColorT, &w->bruteCost, &w->bruteConf, &w->lanczosTmp, &w->staging, &w->stagingB}) {
+      b->release();
+    }
+    (void)hipStreamDestroy(w->stream);
+    (void)hipEventDestroy(w->done);
+    delete w;
+  }
+  if (c->laneReady) {
+    (void)hipEventDestroy(c->laneReady);
   }
   (void)hipStreamDestroy(c->stream);
   (void)hipStreamDestroy(c->copyStream);
@@ -2460,6 +2565,22 @@ int derp_profile_memoised(derp_ctx* c, const char* stage, int level, uint64_t* n
   *n_memoised = m;
   return 0;
 }
+int derp_device_memory(derp_ctx* c, uint64_t* free_bytes, uint64_t* total_bytes) {
+  if (!c) {
+    return 1;
+  }
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t f = 0, t = 0;
+  HIPCHK(c, hipMemGetInfo(&f, &t));
+  if (free_bytes) {
+    *free_bytes = f;
+  }
+  if (total_bytes) {
+    *total_bytes = t;
+  }
+  return 0;
+}
+
 int derp_device_name(derp_ctx* c, char* buf, int n) {
   if (!c || !buf || n <= 0) {
     return 1;

@@ -149,10 +149,19 @@ struct derp_seq {
   unsigned long long bytesSent = 0, bytesRecv = 0;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> exchangeSpans;
   double exchangeMs = 0;
+  // The level's exchange runs on its own stream (round 6): behind an event on the compute stream (every owned frame's raw
+  // level is complete), beside the filter of the owned frames whose windows hold no halo frame. The compute stream waits
+  // for `exchanged` before it filters the other frames and before the Transfer overwrites a raw level a send may still read.
+  hipStream_t xStream = nullptr;
+  hipEvent_t computedEv = nullptr, exchangedEv = nullptr;
+  bool exchangePending = false;                 // an exchange was issued on xStream and the compute stream has not waited for it
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> waitSpans;  // (compute stream reached its wait, exchange finished)
+  double exchangeExposedMs = 0;                 // the part of exchangeMs the compute stream really waited for
   int levelReady = -1;                          // level whose compute finished and whose filter has not run yet
   int levelExchanged = -1;                      // level whose halo disparities have arrived (exchange ran / was marked)
   int computeLevel = -1, computedFrames = 0;    // progress of derp_seq_level_compute_frame over the owned frames
   std::vector<int> computedAt, filteredAt;      // [owned index]: the level whose raw result / filtered scratch the frame holds
+  std::vector<uint64_t> uploaded;               // [owned index * numLevels + level]: destinations uploaded since the level last ran
   std::vector<hipEvent_t> filteredEv;           // [owned index]: recorded behind the frame's filter kernel
   int fovLevel = -1;                            // level q->fov was built for
   // ---- out-of-core mode (resident_frames < owned frames)
@@ -253,7 +262,7 @@ int seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, size_t* 
     }                                                                                            \
   } while (0)
 
-// this rank's sends and receives of one exchange over RCCL: one group on the context's stream
+// this rank's sends and receives of one exchange over RCCL: one group on the exchange stream
 int seq_exchange_rccl(derp_seq* q, int level, int kind) {
   derp_ctx* c = q->c;
   RcclApi* api = rccl_api();
@@ -266,13 +275,13 @@ int seq_exchange_rccl(derp_seq* q, int level, int kind) {
     if (tr.from_rank == q->rank) {
       rc = seq_buffer(q, tr.frame, level, kind, &p, &bytes);
       if (!rc) {
-        r = api->Send(p, bytes, ncclUint8, tr.to_rank, q->comm, c->stream);
+        r = api->Send(p, bytes, ncclUint8, tr.to_rank, q->comm, q->xStream);
         q->bytesSent += bytes;
       }
     } else if (tr.to_rank == q->rank) {
       rc = seq_buffer(q, tr.frame, level, kind, &p, &bytes);
       if (!rc) {
-        r = api->Recv(p, bytes, ncclUint8, tr.from_rank, q->comm, c->stream);
+        r = api->Recv(p, bytes, ncclUint8, tr.from_rank, q->comm, q->xStream);
         q->bytesRecv += bytes;
       }
     }
@@ -320,10 +329,10 @@ int seq_exchange_loopback(derp_seq* q, int level, int kind) {
       return fail(c, "loopback peer %d: %s", tr.from_rank, peer->c->err.c_str());
     }
     TRY(seq_buffer(q, tr.frame, level, kind, &dst, &bd));
-    HIPCHK(c, hipMemcpyAsync(dst, src, bd, hipMemcpyDeviceToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dst, src, bd, hipMemcpyDeviceToDevice, q->xStream));
     q->bytesRecv += bd;
   }
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // pulls are complete before any peer overwrites its level
+  HIPCHK(c, hipStreamSynchronize(q->xStream));  // pulls are complete before any peer overwrites its level
   return 0;
 }
 
@@ -342,11 +351,37 @@ int seq_exchange(derp_seq* q, int level, int kind) {
     (void)hipEventDestroy(ea);
     return fail(c, "hipEventCreate failed");
   }
-  (void)hipEventRecord(ea, c->stream);
+  // the exchange stream starts behind everything the compute stream holds so far (the owned frames' raw levels, or the
+  // uploaded inputs) ...
+  HIPCHK(c, hipEventRecord(q->computedEv, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(q->xStream, q->computedEv, 0));
+  (void)hipEventRecord(ea, q->xStream);
   const int rc = q->transport == SEQ_RCCL ? seq_exchange_rccl(q, level, kind) : seq_exchange_loopback(q, level, kind);
-  (void)hipEventRecord(eb, c->stream);
+  (void)hipEventRecord(eb, q->xStream);
+  (void)hipEventRecord(q->exchangedEv, q->xStream);
   q->exchangeSpans.push_back({ea, eb});  // drained (and destroyed) by derp_seq_stats / derp_seq_destroy
+  // ... and the compute stream waits for it (seq_join_exchange) at the first use of what it delivers
+  q->exchangePending = true;
   return rc;
+}
+
+// the compute stream waits for the exchange in flight (no-op when there is none)
+int seq_join_exchange(derp_seq* q) {
+  derp_ctx* c = q->c;
+  if (!q->exchangePending) {
+    return 0;
+  }
+  hipEvent_t reached = nullptr, done = nullptr;
+  if (hipEventCreate(&reached) == hipSuccess && hipEventCreate(&done) == hipSuccess) {
+    (void)hipEventRecord(reached, c->stream);
+  }
+  HIPCHK(c, hipStreamWaitEvent(c->stream, q->exchangedEv, 0));
+  if (reached && done) {
+    (void)hipEventRecord(done, c->stream);  // right behind the wait: done - reached = what the compute stream stood still for
+    q->waitSpans.push_back({reached, done});
+  }
+  q->exchangePending = false;
+  return 0;
 }
 
 void seq_drain_spans(derp_seq* q) {
@@ -359,6 +394,15 @@ void seq_drain_spans(derp_seq* q) {
     (void)hipEventDestroy(s.second);
   }
   q->exchangeSpans.clear();
+  for (auto& s : q->waitSpans) {
+    (void)hipEventSynchronize(s.second);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s.first, s.second);
+    q->exchangeExposedMs += ms > 0 ? ms : 0;
+    (void)hipEventDestroy(s.first);
+    (void)hipEventDestroy(s.second);
+  }
+  q->waitSpans.clear();
 }
 
 int temporal_space_radius(const derp_seq* q, int level) {
@@ -505,6 +549,11 @@ int derp_seq_create(derp_seq** out, derp_ctx* c, int first, int last, int rank, 
   q->filtered.resize(q->streaming ? 1 : q->owned.size());  // out of core: one frame is filtered, then streamed out
   q->computedAt.assign(q->owned.size(), -1);
   q->filteredAt.assign(q->owned.size(), -1);
+  if (hipStreamCreateWithFlags(&q->xStream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&q->computedEv, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&q->exchangedEv, hipEventDisableTiming) != hipSuccess) {
+    return bail(fail(c, "hipStreamCreate / hipEventCreate failed"));
+  }
   q->filteredEv.assign(q->streaming ? 0 : q->owned.size(), nullptr);
   for (auto& e : q->filteredEv) {
     if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
@@ -591,6 +640,15 @@ void derp_seq_destroy(derp_seq* q) {
       (void)hipEventDestroy(e);
     }
   }
+  if (q->xStream) {
+    (void)hipStreamSynchronize(q->xStream);
+    (void)hipStreamDestroy(q->xStream);
+  }
+  for (hipEvent_t e : {q->computedEv, q->exchangedEv}) {
+    if (e) {
+      (void)hipEventDestroy(e);
+    }
+  }
   q->fov.release();
   q->winMask.release();
   for (auto& v : q->hostDisp) {
@@ -650,6 +708,12 @@ int derp_seq_buffer(derp_seq* q, int frame, int level, int kind, void** ptr, siz
   if (!q || !ptr || !bytes) {
     return 1;
   }
+  {
+    const int jrc = seq_join_exchange(q);
+    if (jrc) {
+      return jrc;
+    }
+  }  // whoever asks for a buffer finds it behind the compute stream, like before round 6
   return seq_buffer(q, frame, level, kind, ptr, bytes);
 }
 
@@ -665,6 +729,7 @@ int derp_seq_buffer_copy(derp_seq* q, int frame, int level, int kind, void* host
     return fail(c, "buffer of frame %d level %d kind %d holds %zu bytes, not %zu", frame, level, kind, sz, bytes);
   }
   HIPCHK(c, hipSetDevice(c->device));
+  TRY(seq_join_exchange(q));
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the level's kernels wrote / will read it on the library's stream
   HIPCHK(c, hipMemcpy(to_device ? p : host, to_device ? host : p, sz, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
   return 0;
@@ -1041,7 +1106,12 @@ int derp_seq_upload_disparity(derp_seq* q, int frame, int level, int d, const fl
     return 0;
   }
   TRY(select_frame(c, k));
-  return derp_upload_disparity(c, level, d, disp);
+  TRY(derp_upload_disparity(c, level, d, disp));
+  if (q->uploaded.size() != q->owned.size() * (size_t)c->numLevels) {
+    q->uploaded.assign(q->owned.size() * (size_t)c->numLevels, 0);
+  }
+  q->uploaded[(size_t)k * c->numLevels + level] |= 1ull << d;
+  return 0;
 }
 
 int derp_seq_download_disparity(derp_seq* q, int frame, int level, int d, float* disp) {
@@ -1087,7 +1157,7 @@ int derp_seq_exchange_inputs_level(derp_seq* q, int level) {
   if (q->opt.use_foreground_masks) {
     TRY(seq_exchange(q, level, 1));
   }
-  return 0;
+  return seq_join_exchange(q);  // inputs: once per sequence, outside every timed region — nothing to overlap with
 }
 
 int derp_seq_exchange_inputs(derp_seq* q) {
@@ -1110,6 +1180,7 @@ int derp_seq_level_compute_frame(derp_seq* q, int level, int frame) {
   }
   derp_ctx* c = q->c;
   HIPCHK(c, hipSetDevice(c->device));
+  TRY(seq_join_exchange(q));  // (a level's filter has joined already: only a caller that skipped it gets here pending)
   const int k = owned_index(q, frame);
   if (k < 0) {
     return fail(c, "frame %d is not owned by rank %d", frame, q->rank);
@@ -1161,9 +1232,14 @@ int derp_seq_level_provided_frame(derp_seq* q, int level, int frame) {
     return fail(c, "derp_seq_level_provided_frame needs the frames resident in HBM");
   }
   TRY(select_frame(c, k));
-  if (!c->haveDisp[level]) {
-    return fail(c, "frame %d has no level %d disparity (derp_seq_upload_disparity of every destination first)", frame, level);
+  // every destination must have been uploaded since this (frame, level) last counted as computed: haveDisp alone is set
+  // by the first plane and survives from an earlier run of the level
+  const uint64_t all = c->D >= 64 ? ~0ull : (1ull << c->D) - 1;
+  const size_t slotLevel = (size_t)k * c->numLevels + level;
+  if (!c->haveDisp[level] || q->uploaded.size() <= slotLevel || (q->uploaded[slotLevel] & all) != all) {
+    return fail(c, "frame %d has no complete level %d disparity (derp_seq_upload_disparity of every destination first)", frame, level);
   }
+  q->uploaded[slotLevel] = 0;
   if (q->computeLevel != level) {
     q->computeLevel = level;
     q->computedFrames = 0;
@@ -1177,11 +1253,64 @@ int derp_seq_level_provided_frame(derp_seq* q, int level, int frame) {
   return 0;
 }
 
+// How many work lanes (derp_ctx::WorkLane) the frames of `level` run on: 0 = one after the other on the context's
+// own working set. Coarse levels only (DERP_SEQ_LANE_MAX_WIDTH, default 256 px), frames resident, every destination's
+// tables in one batch; DERP_SEQ_LANES (default 8) = 0 / 1 switches the lanes off.
+int seq_lane_count(derp_seq* q, int level) {
+  derp_ctx* c = q->c;
+  static const int maxLanes = getenv("DERP_SEQ_LANES") ? atoi(getenv("DERP_SEQ_LANES")) : 8;
+  static const int maxWidth = getenv("DERP_SEQ_LANE_MAX_WIDTH") ? atoi(getenv("DERP_SEQ_LANE_MAX_WIDTH")) : 256;
+  if (q->streaming || maxLanes < 2 || (int)q->owned.size() < 2 || c->LW[level] > maxWidth || c->LH[level] > maxWidth ||
+      getenv("DERP_TABLE_BUDGET_GB")) {
+    return 0;
+  }
+  return std::min(maxLanes, (int)q->owned.size()) - 1;  // the first frame's lane is the context itself
+}
+
 int derp_seq_level_compute(derp_seq* q, int level) {
   if (!q) {
     return 1;
   }
   q->computeLevel = -1;  // a fresh pass over the level
+  derp_ctx* c = q->c;
+  TRY(check_level(c, level));
+  TRY(seq_join_exchange(q));
+  const int lanes = seq_lane_count(q, level);
+  if (lanes > 0) {
+    // The first owned frame runs on the context's own stream and leaves the level's shared tables behind (projection
+    // warps, pixel rays, resampling tables); the other frames follow on the work lanes, behind an event recorded at its
+    // end, and overlap each other. The context's stream then waits for every lane: the exchange and the filter of the
+    // level are ordered behind all frames, as before. Same kernels on the same data as the sequential order.
+    HIPCHK(c, hipSetDevice(c->device));
+    TRY(lanes_prepare(c, lanes, npx(c, level)));
+    for (int k = 0; k < (int)q->owned.size(); ++k) {
+      const int lane = k == 0 ? -1 : (k - 1) % lanes;
+      if (q->computeLevel != level) {
+        q->computeLevel = level;
+        q->computedFrames = 0;
+        q->levelReady = -1;
+      }
+      const int rebuild = c->opt.rebuild_warp_tables;
+      c->opt.rebuild_warp_tables = k == 0 ? rebuild : 0;
+      const int rc = process_level_on_lane(c, lane, k, level);
+      c->opt.rebuild_warp_tables = rebuild;
+      TRY(rc);
+      if (k == 0) {
+        if (c->DB != c->D) {
+          return fail(c, "work lanes need every destination's tables in one batch (level %d: %d of %d)", level, c->DB, c->D);
+        }
+        HIPCHK(c, hipEventRecord(c->laneReady, c->stream));
+      }
+      q->computedAt[k] = level;
+      q->filteredAt[k] = -1;
+      ++q->computedFrames;
+    }
+    for (int i = 0; i < lanes; ++i) {
+      HIPCHK(c, hipStreamWaitEvent(c->stream, c->lanes[i]->done, 0));
+    }
+    q->levelReady = level;
+    return 0;
+  }
   for (int t : q->owned) {
     TRY(derp_seq_level_compute_frame(q, level, t));
   }
@@ -1206,6 +1335,9 @@ int derp_seq_level_exchange(derp_seq* q, int level) {
   TRY(seq_exchange(q, level, 2));
   if (q->transport != SEQ_EXTERNAL) {
     q->levelExchanged = level;
+  }
+  if (q->streaming || getenv("DERP_SEQ_NO_OVERLAP")) {  // (developer A/B: the exchange in line with the compute stream)
+    TRY(seq_join_exchange(q));
   }
   return 0;
 }
@@ -1295,11 +1427,16 @@ int derp_seq_level_filter_frame(derp_seq* q, int level, int frame) {
   }
   int lo, hi;
   seq_window(frame, q->first, q->last, q->opt.time_radius, &lo, &hi);
+  bool needsHalo = false;
   for (int u = lo; u <= hi; ++u) {
     const int ku = owned_index(q, u);
     if (ku >= 0 ? q->computedAt[ku] != level : q->levelExchanged != level) {
       return 2;
     }
+    needsHalo |= ku < 0;
+  }
+  if (needsHalo) {
+    TRY(seq_join_exchange(q));
   }
   Span sp(c, ST_TEMPORAL, level);
   TRY(seq_fov_masks(q, level));
@@ -1354,17 +1491,35 @@ int derp_seq_level_filter(derp_seq* q, int level) {
   Span sp(c, ST_TEMPORAL, level);  // masks + temporal kernels + write-back of every owned frame
   TRY(seq_fov_masks(q, level));
   if (q->streaming) {
+    TRY(seq_join_exchange(q));
     const int radius = temporal_space_radius(q, level);
     TRY(stream_filter_level(q, level, W, H, radius));
     q->levelReady = -1;
     return 0;
   }
-  for (int k = 0; k < (int)q->owned.size(); ++k) {
-    if (q->filteredAt[k] != level) {  // not filtered ahead of time by derp_seq_level_filter_frame
-      TRY(seq_filter_frame(q, level, k));
+  // frames whose windows hold only owned frames first: they run beside the exchange (xStream); then the compute stream
+  // waits for the halo frames' levels and filters the rest
+  for (int pass = 0; pass < 2; ++pass) {
+    if (pass == 1) {
+      TRY(seq_join_exchange(q));
+    }
+    for (int k = 0; k < (int)q->owned.size(); ++k) {
+      if (q->filteredAt[k] == level) {  // filtered ahead of time (derp_seq_level_filter_frame) or in pass 0
+        continue;
+      }
+      int lo, hi;
+      seq_window(q->owned[k], q->first, q->last, q->opt.time_radius, &lo, &hi);
+      bool allOwned = true;
+      for (int u = lo; allOwned && u <= hi; ++u) {
+        allOwned = owned_index(q, u) >= 0;
+      }
+      if (pass == 1 || allOwned) {
+        TRY(seq_filter_frame(q, level, k));
+      }
     }
   }
-  // "Transfer" (pipeline.py:397-408): every owned frame is filtered before any raw level is overwritten
+  // "Transfer" (pipeline.py:397-408): every owned frame is filtered before any raw level is overwritten — and (the join
+  // above) no send of the exchange still reads one
   for (int k = 0; k < (int)q->owned.size(); ++k) {
     SlotView v = slot_view(c, k);
     HIPCHK(c, hipMemcpyAsync((*v.disp)[level].p, q->filtered[k].p, n * c->D * sizeof(float), hipMemcpyDeviceToDevice,
@@ -1413,6 +1568,20 @@ int derp_seq_stats(derp_seq* q, uint64_t* bytes_sent, uint64_t* bytes_received, 
   return 0;
 }
 
+// the part of derp_seq_stats' exchange_ms the compute stream stood still for (the rest ran beside the filter of the
+// frames whose windows are local)
+int derp_seq_exchange_exposed_ms(derp_seq* q, double* exposed_ms) {
+  if (!q) {
+    return 1;
+  }
+  HIPCHK(q->c, hipStreamSynchronize(q->c->stream));
+  seq_drain_spans(q);
+  if (exposed_ms) {
+    *exposed_ms = q->exchangeExposedMs;
+  }
+  return 0;
+}
+
 int derp_seq_stats_reset(derp_seq* q) {
   if (!q) {
     return 1;
@@ -1421,6 +1590,7 @@ int derp_seq_stats_reset(derp_seq* q) {
   seq_drain_spans(q);
   q->bytesSent = q->bytesRecv = 0;
   q->exchangeMs = 0;
+  q->exchangeExposedMs = 0;
   return 0;
 }
 

@@ -62,7 +62,7 @@ EXPORTS = [
     "derp_fov_mask", "derp_layer_disparities", "derp_download_mismatch_mask", "derp_upsample_disparity", "derp_joint_bilateral_u16", "derp_joint_bilateral_f32", "derp_masked_median",
     "derp_temporal_filter", "derp_temporal_filter_dev", "derp_dev_disparity", "derp_dev_color", "derp_dev_mask",
     "derp_get_counters", "derp_reset_counters", "derp_profile_enable", "derp_profile_reset", "derp_profile_query", "derp_profile_memoised",
-    "derp_device_name", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
+    "derp_device_name", "derp_device_memory", "derp_host_nth_element_pairs", "derp_host_minstd_uniform",
     "derp_set_frame_slots", "derp_select_frame", "derp_frame_slots", "derp_host_alloc", "derp_host_free", "derp_bind_thread", "derp_host_register", "derp_host_unregister",
     "derp_seq_options_default", "derp_seq_window", "derp_seq_owner", "derp_seq_plan", "derp_seq_create", "derp_seq_destroy",
     "derp_seq_counts", "derp_seq_frames", "derp_seq_frame_slot", "derp_seq_buffer", "derp_rccl_unique_id",
@@ -70,7 +70,7 @@ EXPORTS = [
     "derp_seq_exchange_inputs", "derp_seq_level_compute", "derp_seq_level_exchange", "derp_seq_level_filter",
     "derp_seq_host_inputs", "derp_seq_buffer_copy", "derp_seq_upload_color_plane", "derp_seq_upload_disparity", "derp_seq_download_disparity", "derp_seq_exchange_inputs_level",
     "derp_seq_level_compute_frame", "derp_seq_level_provided_frame", "derp_seq_mark_exchanged", "derp_seq_level_filter_frame", "derp_seq_download_filtered",
-    "derp_seq_run", "derp_seq_stats", "derp_seq_stats_reset",
+    "derp_seq_run", "derp_seq_stats", "derp_seq_stats_reset", "derp_seq_exchange_exposed_ms",
 ]
 
 _lib = None
@@ -518,6 +518,12 @@ class Derp:
         m = C.c_uint64()
         self._ck(lib().derp_profile_memoised(self.h, stage.encode(), level, C.byref(m)))
         return m.value
+
+    def device_memory(self):
+        """-> (free, total) bytes of HBM right now"""
+        f, t = C.c_uint64(), C.c_uint64()
+        self._ck(lib().derp_device_memory(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
 
     def device_name(self):
         buf = C.create_string_buffer(256)

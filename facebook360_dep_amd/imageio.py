@@ -265,7 +265,8 @@ def load_color_u16(path):
     a = read_image(path)
     if a.dtype == np.float32:  # convertTo(CV_16U, 65535 / 1.0): saturate_cast of the value rounded half to even
         a = np.clip(np.rint(np.nan_to_num(a.astype(np.float64), nan=0.0) * 65535.0), 0, 65535).astype(np.uint16)
-        a = a.reshape(a.shape[0], a.shape[1])
+        if a.ndim == 3 and a.shape[2] == 1:  # (multi-channel floats go through the channel handling below, like convertImage)
+            a = a[..., 0]
     if a.dtype == np.uint8:
         a = a.astype(np.uint16) * 257
     if a.ndim == 2:
@@ -280,7 +281,8 @@ def load_mask(path):
     a = read_image(path)
     if a.dtype == np.float32:  # convertTo(CV_8U, 255 / 1.0), then the threshold
         a = np.clip(np.rint(np.nan_to_num(a.astype(np.float64), nan=0.0) * 255.0), 0, 255).astype(np.uint8)
-        a = a.reshape(a.shape[0], a.shape[1])
+        if a.ndim == 3 and a.shape[2] == 1:
+            a = a[..., 0]
     if a.ndim == 3:
         a = a[..., 1]
     if a.dtype == np.uint16:

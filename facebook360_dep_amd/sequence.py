@@ -424,7 +424,12 @@ class SequenceRunner:
     def stats(self):
         a, b, ms = C.c_uint64(), C.c_uint64(), C.c_double()
         self._ck(derp.lib().derp_seq_stats(self.h, C.byref(a), C.byref(b), C.byref(ms)))
-        return dict(bytes_sent=a.value, bytes_received=b.value + self._received, exchange_ms=ms.value)
+        exposed = C.c_double()
+        self._ck(derp.lib().derp_seq_exchange_exposed_ms(self.h, C.byref(exposed)))
+        # exchange_ms: on the library's exchange stream; exchange_exposed_ms: what the compute stream waited of it (the rest
+        # ran beside the filter of the frames whose windows are local)
+        return dict(bytes_sent=a.value, bytes_received=b.value + self._received, exchange_ms=ms.value,
+                    exchange_exposed_ms=exposed.value)
 
     def stats_reset(self):
         self._received = 0

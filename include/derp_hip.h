@@ -361,6 +361,9 @@ int derp_seq_download_filtered(derp_seq* seq, int frame, int level, int dst, flo
 int derp_seq_run(derp_seq* seq, int level_start, int level_end);
 int derp_seq_stats(derp_seq* seq, uint64_t* bytes_sent, uint64_t* bytes_received, double* exchange_ms);
 int derp_seq_stats_reset(derp_seq* seq);
+/* the part of derp_seq_stats' exchange_ms this rank's compute stream stood still for: a level's exchange runs on its own
+ * stream beside the filter of the owned frames whose windows hold no halo frame (reset by derp_seq_stats_reset) */
+int derp_seq_exchange_exposed_ms(derp_seq* seq, double* exposed_ms);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 /* computeCost evaluations and (evaluation, src) pairs reaching computeSSD since the last reset:
@@ -381,6 +384,9 @@ int derp_profile_query(derp_ctx* ctx, const char* stage, int level, double* ms, 
  * logical n_cost / n_pair above, which count what the reference algorithm issues. */
 int derp_profile_memoised(derp_ctx* ctx, const char* stage, int level, uint64_t* n_memoised);
 int derp_device_name(derp_ctx* ctx, char* buf, int n);
+/* free / total HBM of the context's device right now (hipMemGetInfo): what a host uses to decide how many frames of a
+ * sequence to keep resident (the reference has no counterpart: its working set lives in host memory) */
+int derp_device_memory(derp_ctx* ctx, uint64_t* free_bytes, uint64_t* total_bytes);
 
 /* host-only self checks (no GPU needed): restated libstdc++ algorithms the device code uses */
 int derp_host_nth_element_pairs(float* pairs, int n, int nth);

@@ -423,29 +423,37 @@ def test_destination_subset(small):
 
 def test_destination_batching(small, monkeypatch):
     """Config 4's memory path: when the projection tables of all destinations do not fit the table
-    budget, destinations are processed in batches (DERP_TABLE_BUDGET_GB caps the budget; 12 MB here
-    leaves room for two of the six, 6 MB for one). Results and counters must not depend on the batch size."""
+    budget, destinations are processed in batches (DERP_TABLE_BUDGET_GB caps the budget). Results and counters
+    must not depend on the batch size; the number of batches really taken is read back (one ping-pong span per
+    batch at level 0) so that the test cannot silently stop exercising the batched path."""
     from facebook360_dep_amd import derp
 
     def run():
         g = derp.Derp(small["rig"]["cameras"], partial_coverage=1)
         g.set_pyramid(small["sizes"], small["res"], small["res"])
         g.upload_frame({"color": small["frame"]["color"]})
+        g.profile_enable(True)
         g.process_pyramid()
         g.synchronize()
         out = [[g.download_disparity(level, d) for d in range(small["n"])] for level in range(len(small["sizes"]))]
         c = g.counters()
+        batches = g.profile_query("ping_pong", 0)["launches"]
         g.close()
-        return out, c
+        return out, c, batches
 
-    whole, c_whole = run()
+    whole, c_whole, b_whole = run()
+    assert b_whole == 1
+    seen = []
     for budget in ("0.012", "0.006"):
         monkeypatch.setenv("DERP_TABLE_BUDGET_GB", budget)
-        batched, c_batched = run()
+        batched, c_batched, b = run()
+        seen.append(b)
         assert c_batched == c_whole
-        for a, b in zip(whole, batched):
-            for x, y in zip(a, b):
+        for a, b_ in zip(whole, batched):
+            for x, y in zip(a, b_):
                 assert _float_equal(x, y) == 0
+    print("destination batches at level 0 under 12 MB / 6 MB table budgets:", seen)
+    assert 1 < seen[0] <= seen[1] <= small["n"] and seen[1] > seen[0]
     monkeypatch.setenv("DERP_TABLE_BUDGET_GB", "0.0001")
     g = derp.Derp(small["rig"]["cameras"], partial_coverage=1)
     g.set_pyramid(small["sizes"], small["res"], small["res"])
