@@ -946,14 +946,22 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
   }
   cost /= (float)keep;
   const float trustCoef = 1.0f / (float)keep;
-  const float costFinal = cost * trustCoef / px.confidence;
+  float confidence = px.confidence;
+  if constexpr (RELOAD_RAY) {
+    // like the ray direction: read again where it is used (max(variance, kMinVar) of the pixel) instead of riding through
+    // the source loops, where it was the first value the allocator put in scratch at 128 registers
+    unsigned i = pix;
+    asm("" : "+v"(i) : "v"(cost));
+    confidence = fmaxf((V.srcVar + (size_t)own * ((size_t)V.W * V.H))[i], kMinVar);
+  }
+  const float costFinal = cost * trustCoef / confidence;
 #if DERP_PHASE_TIMERS
   if (tm) {
     const unsigned tc3 = phase_clock();
     tm->proj += tc1 - tc0, tm->ssd += tc2 - tc1, tm->select += tc3 - tc2, tm->inside += tc3 - tc0;
   }
 #endif
-  return make_float2(costFinal, px.confidence);
+  return make_float2(costFinal, confidence);
 }
 
 // gather the per-pixel constants of computeCost: dst ray, 3x3 dst patch, dst bias, variance

@@ -1258,8 +1258,8 @@ int derp_seq_level_provided_frame(derp_seq* q, int level, int frame) {
 // tables in one batch; DERP_SEQ_LANES (default 8) = 0 / 1 switches the lanes off.
 int seq_lane_count(derp_seq* q, int level) {
   derp_ctx* c = q->c;
-  static const int maxLanes = getenv("DERP_SEQ_LANES") ? atoi(getenv("DERP_SEQ_LANES")) : 8;
-  static const int maxWidth = getenv("DERP_SEQ_LANE_MAX_WIDTH") ? atoi(getenv("DERP_SEQ_LANE_MAX_WIDTH")) : 256;
+  const int maxLanes = getenv("DERP_SEQ_LANES") ? atoi(getenv("DERP_SEQ_LANES")) : 8;
+  const int maxWidth = getenv("DERP_SEQ_LANE_MAX_WIDTH") ? atoi(getenv("DERP_SEQ_LANE_MAX_WIDTH")) : 256;
   if (q->streaming || maxLanes < 2 || (int)q->owned.size() < 2 || c->LW[level] > maxWidth || c->LH[level] > maxWidth ||
       getenv("DERP_TABLE_BUDGET_GB")) {
     return 0;

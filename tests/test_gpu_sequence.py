@@ -408,6 +408,42 @@ def test_sequence_frames_filtered_ahead_of_the_level(built):
     g.close()
 
 
+def test_sequence_work_lanes_equal_frame_after_frame(built, monkeypatch):
+    """derp_seq_level_compute runs the frames of a coarse level on work lanes (own working set + stream per frame, the
+    level's warps shared): every level of every frame must equal the frame-after-frame order bit for bit, with and
+    without masks, and with fewer lanes than frames (a lane then takes several frames of the level in turn)."""
+    from facebook360_dep_amd import synth
+
+    n, res, rig, sizes = _setup("small")
+
+    def run(masks, **env):
+        for k in ("DERP_SEQ_LANES", "DERP_SEQ_LANE_MAX_WIDTH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        from facebook360_dep_amd import derp, sequence
+
+        g = derp.Derp(rig["cameras"], partial_coverage=1, use_foreground_masks=int(masks))
+        g.set_pyramid(sizes, res, res)
+        r = sequence.SequenceRunner(g, 0, 5, use_foreground_masks=int(masks))
+        for t in r.owned:
+            r.upload_frame(t, synth.make_frame(rig, sizes, frame=t, seed=360 + t, device="cpu", with_masks=masks))
+        r.run()
+        g.synchronize()
+        out = {(t, lvl): [r.download_disparity(t, lvl, d) for d in range(n)] for t in r.owned for lvl in range(len(sizes))}
+        r.close()
+        g.close()
+        return out
+
+    for masks in (False, True):
+        plain = run(masks, DERP_SEQ_LANES="0")
+        for env in ({}, {"DERP_SEQ_LANES": "3"}, {"DERP_SEQ_LANE_MAX_WIDTH": "100000"}):
+            laned = run(masks, **env)
+            assert plain.keys() == laned.keys()
+            bad = sum(_bad(a, b) for k in plain for a, b in zip(plain[k], laned[k]))
+            assert bad == 0, (masks, env, bad)
+
+
 def test_sequence_phases_out_of_order_are_refused(built):
     """derp_seq_level_filter without the level's compute, or (with halo frames) without its exchange, fails
     instead of filtering stale data."""
