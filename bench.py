@@ -323,8 +323,17 @@ def main():
     launches = max(pp["launches"], 1)
     kernel_ms = pp["ms"] / launches
     memo = g.profile_memoised("ping_pong", 0) / launches
-    stage_ms = {s: round(g.profile_query(s)["ms"] / args.steps, 3) for s in derp.STAGES}
-    level_ms = [round(sum(g.profile_query(s, lv)["ms"] for s in derp.STAGES) / args.steps / max(len(runner.owned), 1), 3)
+    # Levels whose frames ran on overlapping work lanes (derp_seq_level_compute at the coarse levels): their per-stage spans
+    # overlap in time, so those levels are reported by their wall on the context's stream ("lanes_wall") — in
+    # level_ms_per_frame and as stage "coarse_levels_on_lanes" — and left out of the per-stage sums, which therefore still
+    # add up to the step (the temporal stage of every level is exclusive and stays where it was).
+    lanes_wall = [g.profile_query("lanes_wall", lv)["ms"] for lv in range(n_levels)]
+    laned = [lv for lv in range(n_levels) if lanes_wall[lv] > 0]
+    stage_ms = {s: round(sum(g.profile_query(s, lv)["ms"] for lv in range(n_levels)
+                             if lv not in laned or s == "temporal") / args.steps, 3) for s in derp.STAGES}
+    stage_ms["coarse_levels_on_lanes"] = round(sum(lanes_wall) / args.steps, 3)
+    level_ms = [round(((lanes_wall[lv] + g.profile_query("temporal", lv)["ms"]) if lv in laned else
+                       sum(g.profile_query(s, lv)["ms"] for s in derp.STAGES)) / args.steps / max(len(runner.owned), 1), 3)
                 for lv in range(n_levels)]
     cnt = g.counters()
     # ---- what was computed: CRC-32 of every frame's level-0 (filtered) disparity, gathered to rank 0, so that an
@@ -486,6 +495,7 @@ def main():
         "roofline": roofline,
         "stage_ms_per_step": stage_ms,
         "level_ms_per_frame": level_ms,  # all stages of one level of one frame (this rank), finest level first
+        "levels_on_work_lanes": laned,   # their frames overlap: level time = wall / frames, stages under "coarse_levels_on_lanes"
         # CRC-32 (zlib) of each frame's level-0 disparity after the last step, all destinations in rig order, raw
         # float32 bytes: identical for every --gpus N and --partition if the sharded run computed the same depth maps
         "result_crc": crc,

@@ -36,12 +36,13 @@ enum Stage {
   ST_MEDIAN,
   ST_MASKFOV,
   ST_TEMPORAL,
+  ST_LANES,  // wall of a level whose frames ran on overlapping work lanes (their per-stage spans overlap in time)
   ST_COUNT
 };
 const char* kStageNames[ST_COUNT] = {"fov_mask",  "variance",    "own_bias",         "upsample",  "proj_warp",
                                      "reproject", "proj_bias",   "brute_force",      "random_proposals",
                                      "ping_pong", "mismatches",  "bilateral",        "median",    "mask_fov",
-                                     "temporal"};
+                                     "temporal",  "lanes_wall"};
 constexpr int kMaxLevels = 24;
 
 struct DevBuf {

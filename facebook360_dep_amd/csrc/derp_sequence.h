@@ -1283,6 +1283,9 @@ int derp_seq_level_compute(derp_seq* q, int level) {
     // level are ordered behind all frames, as before. Same kernels on the same data as the sequential order.
     HIPCHK(c, hipSetDevice(c->device));
     TRY(lanes_prepare(c, lanes, npx(c, level)));
+    // the per-stage spans of the frames overlap in time on the lanes: this span on the context's stream — from the first
+    // frame's first kernel to the join — is the level's wall ("lanes_wall")
+    Span wall(c, ST_LANES, level);
     for (int k = 0; k < (int)q->owned.size(); ++k) {
       const int lane = k == 0 ? -1 : (k - 1) % lanes;
       if (q->computeLevel != level) {

@@ -373,7 +373,8 @@ int derp_reset_counters(derp_ctx* ctx);
 /* per-stage HIP-event timing on the context's own stream, plus per-stage computeCost counters.
  * stage names: "fov_mask", "variance", "own_bias", "upsample", "proj_warp", "reproject",
  * "proj_bias", "brute_force", "random_proposals", "ping_pong", "mismatches", "bilateral", "median", "mask_fov", "temporal" (the
- * sequence driver's filter + Transfer).
+ * sequence driver's filter + Transfer), "lanes_wall" (a coarse level whose frames derp_seq_level_compute ran on overlapping
+ * work lanes: the level's wall on the context's stream — the per-stage spans of such a level overlap in time).
  * level = -1 aggregates all levels. ms / launches / n_cost / n_pair may be NULL. */
 int derp_profile_enable(derp_ctx* ctx, int on);
 int derp_profile_reset(derp_ctx* ctx);

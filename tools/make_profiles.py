@@ -142,6 +142,7 @@ def issue_model(kernel, view):
     m = valu_model.issue_cycles(counts, valu_model.static_mix(kernel), costs)
     out = {"issue_cycles_per_launch": m["cycles_upper"], "issue_cycles_if_simple_ops_coissue": m["cycles_lower"],
            "instructions_by_class": m["by_class"], "instructions_by_counter": m["dynamic_by_counter"],
+           "class_split_sensitivity": m["class_split_sensitivity"],
            "class_cycles_used": costs}
     ms = max_ms(kernel)
     if ms:

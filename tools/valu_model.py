@@ -168,7 +168,15 @@ def issue_cycles(counts, mix, costs):
     upper = sum(by_class[c] * costs[c] for c in by_class)
     hidden = min(by_class["S"], by_class["F"])
     lower = upper - hidden * costs["S"]
+    # The split between S and F INSIDE a typed counter (and inside "other") is the static-mix heuristic above, not a
+    # measurement: how much the result depends on it = the same pricing with 10 % of the S + F instructions moved from one
+    # class to the other.
+    sf = by_class["S"] + by_class["F"]
+    shift = 0.1 * sf * (costs["F"] - costs["S"])
+    sens = {"shift": "10 % of the S + F instructions re-classed", "cycles_upper_if_more_F": upper + shift,
+            "cycles_upper_if_more_S": upper - shift, "relative": round(shift / upper, 4) if upper else None}
     return {"cycles_upper": upper, "cycles_lower": lower, "by_class": {c: by_class[c] for c in sorted(by_class)},
+            "class_split_sensitivity": sens,
             "dynamic_by_counter": dyn,
             "static_class_share_by_counter": {c: {k: round(v / float(sum(sh.values())), 3) for k, v in sh.items()}
                                               for c, sh in sorted(share.items())}}
