@@ -53,6 +53,12 @@ def test_bench_single_process_small(built):
     assert out["config2_single_frame"]["value"] > 0
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["config1_full"]["value"] > 0
     assert out["stage_ms_per_step"]["temporal"] > 0
+    # stdout carries the line and nothing else (whatever a library prints goes to stderr)
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    # the `small` rig's levels all run on work lanes: reported by their wall, and the stage times still add up to the step
+    assert out["levels_on_work_lanes"] and out["stage_ms_per_step"]["coarse_levels_on_lanes"] > 0
+    assert sum(out["stage_ms_per_step"].values()) <= 1.02 * out["ms_per_step"]
+    assert out["config"]["halo_exchange"]["ms_per_step_exposed"] == 0.0  # one rank: nothing is exchanged
     # what was computed: the CPU oracle's CRCs for this workload
     assert out["result_crc"] == _oracle_crc_small(4) and out["halo_transport_per_rank"] == ["local"]
 

@@ -408,6 +408,28 @@ def test_sequence_frames_filtered_ahead_of_the_level(built):
     g.close()
 
 
+def test_sequence_exchange_stream_statistics(built):
+    """The level's exchange runs on the library's exchange stream; what the compute stream waited of it cannot exceed what the
+    exchange took, a rank with halo frames reports both, and `derp_device_memory` answers with the device's free / total HBM."""
+    from facebook360_dep_amd import sequence
+
+    n, res, rig, sizes = _setup("tiny")
+    made = [_gpu_runner(rig, sizes, res, FIRST, LAST, rank, 2) for rank in range(2)]
+    sequence.run_loopback([r for (_, r) in made], len(sizes) - 1)
+    for g, r in made:
+        g.synchronize()
+        st = r.stats()
+        assert st["bytes_received"] > 0 and st["exchange_ms"] > 0
+        assert 0.0 <= st["exchange_exposed_ms"] <= st["exchange_ms"] + 0.5
+        free, total = g.device_memory()
+        assert 0 < free <= total and total > (64 << 30)
+    ref = _oracle_sequence("tiny", FIRST, LAST)
+    assert _compare_with_oracle([r for (_, r) in made], ref, n, sizes) == 0
+    for g, r in made:
+        r.close()
+        g.close()
+
+
 def test_sequence_work_lanes_equal_frame_after_frame(built, monkeypatch):
     """derp_seq_level_compute runs the frames of a coarse level on work lanes (own working set + stream per frame, the
     level's warps shared): every level of every frame must equal the frame-after-frame order bit for bit, with and
