@@ -638,6 +638,15 @@ size_t lds_for_waves(size_t needed, int waves, size_t ldsPerCu, size_t fixed) {
   return std::max(needed, perBlock > fixed ? perBlock - fixed : needed);
 }
 constexpr size_t kCostLdsStatic = sizeof(PatchWin) * (DERP_COST_BLOCK / 64) + kAtanLutDoubles * sizeof(double);
+// Which register budget of the two cost kernels to launch (k_ping_pong / k_random_proposals vs their _w3 twins): four waves
+// per SIMD need sixteen one-wave blocks per CU, i.e. LDS for sixteen — true up to 16 cameras (9.3 KB each of 160 KB; measured
+// 3.9 resident waves), not beyond (24 cameras: 13.3 KB, twelve blocks). DERP_COST_WAVES=3 / 4 forces one (developer A/B).
+bool cost_four_waves(const derp_ctx* c) {
+  if (const char* e = getenv("DERP_COST_WAVES")) {
+    return atoi(e) >= 4;
+  }
+  return 16 * (kCostLdsPerSrc * (size_t)c->S + kCostLdsStatic) <= c->ldsPerCu && c->S <= 16;
+}
 
 int run_brute_force(derp_ctx* c, int dst0, int nd) {
   const int L = c->cur;
@@ -679,8 +688,8 @@ int run_random_proposals(derp_ctx* c, int dst0, int nd) {
   int tilesX;
   const int tiles = tiles_of(V.W, V.H, tilesX);
   const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->randomWaves, c->ldsPerCu, kCostLdsStatic);
-  hipLaunchKernelGGL(k_random_proposals, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->rank.as<int>(),
-                     tilesX, tiles);
+  hipLaunchKernelGGL(cost_four_waves(c) ? k_random_proposals : k_random_proposals_w3, dim3(round8(tiles), nd),
+                     dim3(DERP_COST_BLOCK), lds, c->stream, V, c->rank.as<int>(), tilesX, tiles);
   KCHECK(c);
   return 0;
 }
@@ -698,8 +707,8 @@ int run_ping_pong(derp_ctx* c, int dst0, int nd) {
   const int tiles = tiles_of(V.W, V.H, tilesX);
   const size_t lds = lds_for_waves(kCostLdsPerSrc * (size_t)(c->S), c->ppWaves, c->ldsPerCu, kCostLdsStatic);
   for (int it = 1; it <= c->opt.ping_pong_iterations; ++it) {
-    hipLaunchKernelGGL(k_ping_pong, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds, c->stream, V, c->changed.as<uint8_t>(),
-                       c->dispRes.as<float>(), c->costRes.as<float>(), tilesX,
+    hipLaunchKernelGGL(cost_four_waves(c) ? k_ping_pong : k_ping_pong_w3, dim3(round8(tiles), nd), dim3(DERP_COST_BLOCK), lds,
+                       c->stream, V, c->changed.as<uint8_t>(), c->dispRes.as<float>(), c->costRes.as<float>(), tilesX,
                        (int)(it == 1 && c->randomRanThisLevel && !c->noMemo));
     KCHECK(c);
     hipLaunchKernelGGL(k_ping_pong_commit, dim3(flat_grid(n * nd)), dim3(256), 0, c->stream,

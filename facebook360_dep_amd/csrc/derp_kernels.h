@@ -1634,8 +1634,8 @@ __global__ void __launch_bounds__(256) k_row_rank(LevelView V, int* __restrict__
   }
 }
 
-__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
-    k_random_proposals(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
+// (the body of k_random_proposals / k_random_proposals_w3: the same code under two register budgets, see below)
+__device__ __forceinline__ void random_proposals_body(const LevelView& V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
   extern __shared__ SsdPair ldsPairs[];
   const int dl = blockIdx.y;
   const int d = V.dst0 + dl;
@@ -1733,14 +1733,27 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
 #endif
 }
 
+// Two register budgets for the same body. Up to 16 cameras a wave's LDS (8 B x 64 lanes x S pair slots + the patch window)
+// lets sixteen one-wave blocks share a CU: the kernels are held to 128 VGPRs = FOUR waves per SIMD. With more cameras the
+// pair slots fill the LDS first (24 cameras: twelve blocks = three waves) and the 128-register build would pay its spills
+// and tighter schedule for nothing: the _w3 kernels keep the 168 registers of three waves (config 4, same box: 261 -> 271
+// Mpix/s, profiles/r06_kernel_variants.txt run 9). The launcher picks by camera count (cost_four_waves, derp_capi.hip).
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_RANDOM_MIN_WAVES)
+    k_random_proposals(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
+  random_proposals_body(V, rank, tilesX, tilesPerDst);
+}
+__global__ void __launch_bounds__(DERP_COST_BLOCK, 3)
+    k_random_proposals_w3(LevelView V, const int* __restrict__ rank, int tilesX, int tilesPerDst) {
+  random_proposals_body(V, rank, tilesX, tilesPerDst);
+}
+
 // ----------------------------------------------------------------------------------------
 // ping-pong propagation — Derp.cpp:403-538. Jacobi: reads disparity, writes dispRes / costRes.
 // ----------------------------------------------------------------------------------------
 __constant__ int kCandidates[9][2] = {{0, 0}, {-1, 0}, {1, 0}, {0, -1}, {0, 1}, {-2, -2}, {2, -2}, {-2, 2}, {2, 2}};
 
-__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
-    k_ping_pong(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
-                float* __restrict__ costRes, int tilesX, int useMemo) {
+__device__ __forceinline__ void ping_pong_body(const LevelView& V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
+                                               float* __restrict__ costRes, int tilesX, int useMemo) {
   extern __shared__ SsdPair ldsPairs[];
   const int dl = blockIdx.y;
   const int d = V.dst0 + dl;
@@ -1846,6 +1859,17 @@ __global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
   if ((threadIdx.x & 63) == 0 && nMemo) {
     atomicAdd(&V.counters[3], (unsigned long long)nMemo);
   }
+}
+
+__global__ void __launch_bounds__(DERP_COST_BLOCK, DERP_COST_MIN_WAVES)
+    k_ping_pong(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
+                float* __restrict__ costRes, int tilesX, int useMemo) {
+  ping_pong_body(V, changed, dispRes, costRes, tilesX, useMemo);
+}
+__global__ void __launch_bounds__(DERP_COST_BLOCK, 3)  // more than 16 cameras: see k_random_proposals_w3
+    k_ping_pong_w3(LevelView V, const uint8_t* __restrict__ changed, float* __restrict__ dispRes,
+                   float* __restrict__ costRes, int tilesX, int useMemo) {
+  ping_pong_body(V, changed, dispRes, costRes, tilesX, useMemo);
 }
 
 // changed = disp != dispRes; dispRes -> disp; costRes -> cost (Derp.cpp:527-529)

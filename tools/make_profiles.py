@@ -64,10 +64,17 @@ for f in ("_bench.json", "_bench_under_rocprof.json"):
         shutil.copy(os.path.join(src, tag + f), os.path.join(dst, tag + f))
 
 
+def names_of(kernel):
+    """A cost kernel exists under two register budgets (k_ping_pong / k_ping_pong_w3, derp_kernels.h): a run launches one of
+    them, chosen by the rig's camera count — look for the name given, then for its _w3 twin."""
+    return [kernel, kernel.replace("(", "_w3(") if kernel.endswith("(") else kernel + "_w3"]
+
+
 def val(group, kernel, counter, field):
-    for k, v in pm.get(group, {}).items():
-        if kernel in k and counter in v:
-            return v[counter][field]
+    for name in names_of(kernel):
+        for k, v in pm.get(group, {}).items():
+            if name in k and counter in v and v[counter].get("max", 0.0) > 0:
+                return v[counter][field]
     return 0.0
 
 
@@ -116,12 +123,13 @@ UBENCH = os.path.join(dst, "r04_ubench.jsonl")
 
 def max_ms(kernel):
     """duration of the longest dispatch of `kernel` in the kernel trace (= its level-0 launch)"""
-    for r in keep:
-        if kernel in r[0]:
-            try:
-                return float(r[hdr.index("MaxNs")]) / 1e6
-            except (ValueError, IndexError):
-                return None
+    for name in names_of(kernel):
+        for r in keep:
+            if name in r[0]:
+                try:
+                    return float(r[hdr.index("MaxNs")]) / 1e6
+                except (ValueError, IndexError):
+                    return None
     return None
 
 
@@ -129,20 +137,24 @@ def issue_model(kernel, view):
     """tools/valu_model.py on the typed VALU counters of the level-0 launch: SIMD issue cycles per launch."""
     if "VALU_F32" not in pm or "VALU_F64" not in pm or not os.path.exists(UBENCH):
         return None
-    counts = {}
-    for grp in ("VALU_F32", "VALU_F64"):
-        for k, v in pm[grp].items():
-            if kernel in k:
-                for c, x in v.items():
-                    counts[c.replace("SQ_INSTS_VALU_", "").replace("SQ_INSTS_VALU", "VALU")] = x["max"]
+    counts, used = {}, kernel
+    for name in names_of(kernel):
+        for grp in ("VALU_F32", "VALU_F64"):
+            for k, v in pm[grp].items():
+                if name in k and v.get("SQ_INSTS_VALU", v.get("SQ_WAVE_CYCLES", {})).get("max", 0.0) > 0:
+                    for c, x in v.items():
+                        counts[c.replace("SQ_INSTS_VALU_", "").replace("SQ_INSTS_VALU", "VALU")] = x["max"]
+        if counts.get("VALU"):
+            used = name
+            break
     if not counts.get("VALU"):
         return None
     waves = view.get("waves_per_simd_avg") or 3
     costs = valu_model.class_costs(UBENCH, waves)
-    m = valu_model.issue_cycles(counts, valu_model.static_mix(kernel), costs)
+    m = valu_model.issue_cycles(counts, valu_model.static_mix(used), costs)
     out = {"issue_cycles_per_launch": m["cycles_upper"], "issue_cycles_if_simple_ops_coissue": m["cycles_lower"],
            "instructions_by_class": m["by_class"], "instructions_by_counter": m["dynamic_by_counter"],
-           "class_split_sensitivity": m["class_split_sensitivity"],
+           "class_split_sensitivity": m["class_split_sensitivity"], "kernel_symbol_priced": used,
            "class_cycles_used": costs}
     ms = max_ms(kernel)
     if ms:
@@ -190,7 +202,7 @@ for short, kname in (("random", "k_random_proposals"),):  # the same fields for 
         entry[short + "_level0_class_cycles"] = im["class_cycles_used"]
     l2 = pm.get("L2", {})
     for k, x in l2.items():
-        if kname in k and "TCC_REQ_sum" in x:
+        if kname in k and "TCC_REQ_sum" in x and x["TCC_REQ_sum"]["max"] > 0:
             req, miss = x["TCC_REQ_sum"]["max"], x.get("TCC_MISS_sum", {}).get("max", 0.0)
             entry[short + "_level0_l2"] = {"requests": req, "misses": miss, "hit_rate": round(1.0 - miss / max(req, 1.0), 4)}
 ppm = entry["kernels_level0_launch"]["k_ping_pong("].get("issue_model")
@@ -205,7 +217,7 @@ entry["whole_step_hbm_fetch_bytes"] = 2.0 * 1024.0 * sum(v["FETCH_SIZE"]["sum"] 
 entry["whole_step_hbm_write_bytes"] = 1024.0 * sum(v["WRITE_SIZE"]["sum"] for v in pm.get("WRITE_SIZE", {}).values())
 # effective clock of the profiled level-0 launch: GRBM cycles / its duration in the kernel trace (max duration row)
 for r in keep:
-    if "k_ping_pong(" in r[0] and pp.get("chip_busy_cycles_per_launch"):
+    if ("k_ping_pong(" in r[0] or "k_ping_pong_w3(" in r[0]) and pp.get("chip_busy_cycles_per_launch"):
         try:
             max_ns = float(r[hdr.index("MaxNs")])
             entry["ping_pong_level0_trace_max_ms"] = max_ns / 1e6

@@ -127,7 +127,9 @@ def static_mix(kernel, trips=8.0):
     block the compiler marks "in Loop: ... Depth=d" weighs trips^d (the cost kernels run ~6.5 sources per
     candidate and 8-9 candidates per pixel; the filters walk windows of >= 9 taps)."""
     text = device_asm()
-    m = re.search(r"^(_Z\w*%s\w*):" % re.escape(kernel.rstrip("(<")), text, re.M)
+    # (k_ping_pong must not find k_ping_pong_w3 or k_ping_pong_commit: the name is followed by the mangled parameter list, "E...")
+    m = re.search(r"^(_ZN4derp\d+%sE\w*):" % re.escape(kernel.rstrip("(<")), text, re.M) or \
+        re.search(r"^(_Z\w*%s\w*):" % re.escape(kernel.rstrip("(<")), text, re.M)
     if not m:
         return Counter()
     body = text[m.end():]
