@@ -463,6 +463,32 @@ def test_destination_batching(small, monkeypatch):
     g.close()
 
 
+def test_cost_kernel_register_budgets_agree(small, monkeypatch):
+    """k_ping_pong / k_random_proposals exist under two register budgets — four waves per SIMD (128 VGPRs, up to 16 cameras)
+    and three (their _w3 twins, what rigs beyond 16 cameras launch: the pair slots bound the occupancy through LDS there).
+    Same body: forced either way (DERP_COST_WAVES) a pyramid must come out bit for bit the same, counters included."""
+    from facebook360_dep_amd import derp
+
+    def run(waves):
+        monkeypatch.setenv("DERP_COST_WAVES", waves)
+        g = derp.Derp(small["rig"]["cameras"], partial_coverage=1)
+        g.set_pyramid(small["sizes"], small["res"], small["res"])
+        g.upload_frame({"color": small["frame"]["color"]})
+        g.process_pyramid()
+        g.synchronize()
+        out = [[g.download_disparity(level, d) for d in range(small["n"])] for level in range(len(small["sizes"]))]
+        c = g.counters()
+        g.close()
+        return out, c
+
+    four, c4 = run("4")
+    three, c3 = run("3")
+    assert c3 == c4
+    for a, b in zip(four, three):
+        for x, y in zip(a, b):
+            assert _float_equal(x, y) == 0
+
+
 def test_sixteen_camera_rig_full_pyramid(built):
     """BASELINE config 2's camera count (16 on a Fibonacci sphere, up to 15 sources per cost, which
     exercises every branch of the nth_element restatement) at a size the oracle finishes in seconds."""
