@@ -105,6 +105,30 @@ __device__ __forceinline__ double sk(double v) {
   asm("" : "+s"(v));
   return v;
 }
+// sqrt(x) exactly as the compiler expands llvm.sqrt.f64 on this target (scale tiny arguments by 2^256, v_rsq_f64, one
+// Goldschmidt step on (g, h), two residual corrections, scale back by 2^-128, pass +-0 / +inf through) — operation for
+// operation, so the same bits — but without its three 32-bit literals: the expansion selects 256 / -128 with v_cndmask,
+// which (vcc + one scalar = the constant-bus limit) forces them, and the class mask, into vector registers that then
+// ride through every loop of the cost kernels. Here the exponents come from the comparison bit by shifts and the mask
+// sits in a scalar register: three more 32-bit instructions per projection, three VGPRs fewer everywhere.
+__device__ __forceinline__ double sqrt_lean(double x) {
+  const int scaled = (int)(x < sk(0x1.0p-767));
+  const double xs = __builtin_ldexp(x, scaled << 8);
+  const double y = __builtin_amdgcn_rsq(xs);
+  double g = xs * y;
+  double h = y * 0.5;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  double d = __builtin_fma(-g, g, xs);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, xs);
+  g = __builtin_fma(d, h, g);
+  const double res = __builtin_ldexp(g, -(scaled << 7));
+  int mask = 0x260;  // +-0 and +inf
+  asm("" : "+s"(mask));
+  return __builtin_amdgcn_class(xs, mask) ? xs : res;
+}
 __device__ __forceinline__ double atan2_ypos(double y, double x) {
   const double ax = fabs(x);
   const bool c0 = y < 0.4375 * ax, c1 = y < 0.6875 * ax, c2 = y < 1.1875 * ax, c3 = y < 2.4375 * ax;
@@ -188,6 +212,13 @@ __device__ __forceinline__ double atan2_ypos_lut(double y, double x, const doubl
 
 // Camera.h:301-341. LEAN (device, cost kernels only): fp64 atan2 / division through the routines above
 // (1 = interval constants from scalar literals, 2 = from the table `atanLut` in LDS).
+// LEAN: bits 0-1 = the short atan2 / division (1: constants from scalar literals, 2: from the LDS table); bit 2 = square
+// roots through sqrt_lean in every camera type (the same bits as sqrt(), none of its vector-register literals)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DERP_SQRT(x) ((LEAN & 4) ? sqrt_lean(x) : sqrt(x))
+#else
+#define DERP_SQRT(x) sqrt(x)
+#endif
 template <int LEAN = 0>
 DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = nullptr) {
 #ifdef DERP_MIX_HOT_ONLY
@@ -195,19 +226,21 @@ DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = n
 #else
   if (c.type == DERP_FTHETA) {
 #endif
-    const double xy = sqrt(p.x * p.x + p.y * p.y);
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (LEAN) {
-      const double r = LEAN == 2 ? atan2_ypos_lut(xy, -p.z, atanLut) : atan2_ypos(xy, -p.z);
+    const double xy = DERP_SQRT(p.x * p.x + p.y * p.y);
+    if (LEAN & 3) {
+      const double r = (LEAN & 3) == 2 ? atan2_ypos_lut(xy, -p.z, atanLut) : atan2_ypos(xy, -p.z);
       const double s = div_plain(distort(c, r), xy);
       return {s * p.x, s * p.y};
     }
+#else
+    const double xy = sqrt(p.x * p.x + p.y * p.y);
 #endif
     const double r = atan2(xy, -p.z);
     const double s = distort(c, r) / xy;
     return {s * p.x, s * p.y};
   } else if (c.type == DERP_RECTILINEAR) {
-    const double xy = sqrt(p.x * p.x + p.y * p.y);
+    const double xy = DERP_SQRT(p.x * p.x + p.y * p.y);
     double r;
     if (-p.z <= 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -221,19 +254,19 @@ DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = n
     const double s = distort(c, r) / xy;
     return {s * p.x, s * p.y};
   } else if (c.type == DERP_EQUISOLID) {
-    const double xy = sqrt(p.x * p.x + p.y * p.y);
-    const double n = sqrt(sum3(p.x * p.x, p.y * p.y, p.z * p.z));
-    const double r = 2 * sqrt((1 + p.z / n) / 2);
+    const double xy = DERP_SQRT(p.x * p.x + p.y * p.y);
+    const double n = DERP_SQRT(sum3(p.x * p.x, p.y * p.y, p.z * p.z));
+    const double r = 2 * DERP_SQRT((1 + p.z / n) / 2);
     const double s = distort(c, r) / xy;
     return {s * p.x, s * p.y};
   } else {
     double px, py;
     if (p.z < 0) {
-      const double n = sqrt(sum3(p.x * p.x, p.y * p.y, p.z * p.z));
+      const double n = DERP_SQRT(sum3(p.x * p.x, p.y * p.y, p.z * p.z));
       px = p.x / n;
       py = p.y / n;
     } else {
-      const double n = sqrt(p.x * p.x + p.y * p.y);
+      const double n = DERP_SQRT(p.x * p.x + p.y * p.y);
       px = p.x / n;
       py = p.y / n;
     }
@@ -242,6 +275,7 @@ DERP_HD D2 camera_to_sensor(const Cam& c, const D3& p, const double* atanLut = n
   }
 }
 
+#undef DERP_SQRT
 // Camera.h:344-378
 DERP_HD D3 sensor_to_camera(const Cam& c, const D2& s) {
   const double sq = s.x * s.x + s.y * s.y;

@@ -21,6 +21,8 @@
 #include <math.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "derp_camera.h"
 #include "gcc_algos.h"
 
@@ -183,6 +185,13 @@ __device__ __forceinline__ size_t tiled_index(int tilesX, int ox, int oy) {
 }
 __device__ __forceinline__ int slot(int s, int own) {
   return s < own ? s : s - 1;
+}
+// element `i` of a per-destination plane through a 32-bit BYTE offset from its (wave-uniform) base: the access keeps the
+// scalar-base + 32-bit-offset form, and no 64-bit per-lane address (a register pair the allocator parks in scratch) exists.
+// A plane is far below 4 GB.
+template <typename T>
+__device__ __forceinline__ T& at32(T* base, unsigned i) {
+  return *reinterpret_cast<T*>(reinterpret_cast<char*>(const_cast<typename std::remove_const<T>::type*>(base)) + i * (unsigned)sizeof(T));
 }
 
 // XCD-aware tile order: consecutive block ids round-robin over the 8 XCDs, so give block b
@@ -832,7 +841,11 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
     unsigned i = pix;
     asm("" : "+v"(i) : "v"(disparity));
     const double* rd = V.rayDir + (size_t)(V.dst0 + dl) * ((size_t)V.W * V.H);
-    rayD = {rd[i], rd[V.rayStride + i], rd[2 * V.rayStride + i]};
+    if constexpr (RANDOM) {  // (32-bit byte offsets from three scalar bases: no 64-bit per-lane index)
+      rayD = {at32(rd, i), at32(rd + V.rayStride, i), at32(rd + 2 * V.rayStride, i)};
+    } else {
+      rayD = {rd[i], rd[V.rayStride + i], rd[2 * V.rayStride + i]};
+    }
   }
   const D3 pWorld = {px.rayO.x + rayD.x * depth, px.rayO.y + rayD.y * depth, px.rayO.z + rayD.z * depth};
   const size_t wPlane = warp_plane(V), cPlane = color_plane(V);
@@ -878,7 +891,8 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
       pn.y = 0.5 + 0.45 * (double)(fy - floorf(fy) - 0.5f);
       const bool vis = (s & 1) != 0;
 #else
-      const bool vis = sees<(DERP_LEAN_PROJ != 0) * (DERP_ATAN_LUT ? 2 : 1)>(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1],
+      // (bit 2: square roots through sqrt_lean — random proposals, where its three registers decide between scratch and none)
+      const bool vis = sees<(DERP_LEAN_PROJ != 0) * ((DERP_ATAN_LUT ? 2 : 1) + (RANDOM ? 4 : 0))>(cs, pWorld, cs.principal[0], cs.principal[1], cs.focal[0], cs.focal[1],
                                                  1.0, 1.0, pn, pairs.atanLut);
 #endif
       if (__ballot(pend) != 0ull) {
@@ -952,7 +966,11 @@ __device__ __forceinline__ float2 compute_cost(const LevelView& V, int dl, int o
     // the source loops, where it was the first value the allocator put in scratch at 128 registers
     unsigned i = pix;
     asm("" : "+v"(i) : "v"(cost));
-    confidence = fmaxf((V.srcVar + (size_t)own * ((size_t)V.W * V.H))[i], kMinVar);
+    if constexpr (RANDOM) {
+      confidence = fmaxf(at32(V.srcVar + (size_t)own * ((size_t)V.W * V.H), i), kMinVar);
+    } else {
+      confidence = fmaxf((V.srcVar + (size_t)own * ((size_t)V.W * V.H))[i], kMinVar);
+    }
   }
   const float costFinal = cost * trustCoef / confidence;
 #if DERP_PHASE_TIMERS
@@ -1674,15 +1692,17 @@ __device__ __forceinline__ void random_proposals_body(const LevelView& V, const 
         // read again per proposal.
         // One copy of computeCost serves the evaluation of the current disparity (i = -1) and the proposals: the kernel's
         // code is half the size it was with two inlined copies (45 KB against a 64 KB instruction cache).
-        float currDisp = disp[idx];
-        float currCost = 0.f, currConf = 0.f, costThresh = 0.f, amplitude = 0.f;
-        unsigned currPairs = 0;  // (no store inside the loop: a store's acknowledgement would sit in front of every later load's wait)
+        float currDisp = at32(disp, idx);
+        float currCost = 0.f, costThresh = 0.f, amplitude = 0.f;
+        // the confidence and pair count of the current best ride in the lane's spare pair slot (S slots are allocated, S - 1
+        // sources use them): results, read back once after the loop
+        const int spare = V.S - 1;
         const float maxDisp = 1.0f / V.minDepthM;
-        uint32_t state = (uint32_t)(rank + (size_t)d * n)[idx];  // minstd_rand0 positioned by k_row_rank
+        uint32_t state = (uint32_t)at32(rank + (size_t)d * n, idx);  // minstd_rand0 positioned by k_row_rank
         for (int i = -1; i < V.randomProposals; ++i) {
           unsigned pi = idx;
           asm("" : "+v"(pi) : "s"(i));  // (opaque per proposal: the loads below stay inside the loop)
-          const float minDisp = V.hasFg ? (V.bgDisp + (size_t)d * n)[pi] : (1.0f / V.maxDepthM);
+          const float minDisp = V.hasFg ? at32(V.bgDisp + (size_t)d * n, pi) : (1.0f / V.maxDepthM);
           float propDisp = currDisp;
           if (i >= 0) {
             const float lo = fmaxf(minDisp, currDisp - amplitude), hi = fminf(maxDisp, currDisp + amplitude);
@@ -1705,15 +1725,19 @@ __device__ __forceinline__ void random_proposals_body(const LevelView& V, const 
           if (take) {
             currCost = pr.x;
             currDisp = propDisp;
-            currConf = pr.y;
-            currPairs = np;
+            pairs.set(spare, SsdPair{pr.y, __uint_as_float(np)});
           }
         }
-        (V.confidence + (size_t)d * n)[idx] = currConf;
-        (V.pairCount + (size_t)d * n)[idx] = (uint8_t)currPairs;
+        {
+          unsigned pi = idx;
+          asm("" : "+v"(pi) : "v"(currCost));
+          const SsdPair best = pairs.get(spare);
+          at32(V.confidence + (size_t)d * n, pi) = best.first;
+          at32(V.pairCount + (size_t)d * n, pi) = (uint8_t)__float_as_uint(best.second);
+          at32(disp, pi) = currDisp;
+          at32(V.cost + (size_t)d * n, pi) = currCost;
+        }
         nCost = 1u + (unsigned)max(V.randomProposals, 0);
-        disp[idx] = currDisp;
-        (V.cost + (size_t)d * n)[idx] = currCost;
       }
     }
   }
